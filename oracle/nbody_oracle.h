@@ -1,0 +1,75 @@
+/* oracle/nbody_oracle.h -- TEST INFRASTRUCTURE ONLY (checker + timed CPU baseline), never the product path.
+ *
+ * CPU restatement ("port") of the reference's step semantics for the hot path:
+ *   areParticlesColliding  /root/reference/src/nbody.cu:126-134
+ *   ComputeForces          /root/reference/src/nbody.cu:139-271
+ *   MoveBodies             /root/reference/src/nbody.cu:277-292
+ *   launch geometry        /root/reference/src/nbody.cu:473,481-483
+ *   host compaction        /root/reference/src/nbody.cu:488-510
+ *   Vec2f rounding order   /root/reference/include/vec2f.h:45-93
+ *
+ * Pinning: the reference holds no tests or golden vectors.  This restatement is pinned
+ * against the reference ITSELF: oracle/_ref/libnbody_ref.so runs the reference's own kernel text on the CPU
+ * (oracle/ref_shim), tests/golden/ holds vectors generated from it (tests/golden/make_golden.py), and
+ * tests/test_oracle_vs_ref.py checks bit-equality of this file against both.  The fp64 variant has no
+ * reference at all (the reference has no fp64 kernel): "parity unpinned" for fp64.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ */
+#ifndef NBODY_ORACLE_H
+#define NBODY_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORACLE_LITERAL = 0, ORACLE_CLEAN = 1 };
+
+typedef struct oracle_stats {
+    int64_t pairs;      /* ordered (i,j) pairs evaluated by the stepper in this call        */
+    int32_t n_absorb;   /* |E_t| : (i,j) with hit and Mi >= Mj               */
+    int32_t n_deleted;  /* |D_t| : i with some hit and Mi <  Mj                              */
+    int32_t n_active;   /* bodies that were updated (literal: i < (N/128)*128, src :473)     */
+    int32_t n_after;    /* survivor count after compaction (full-step entry points only)     */
+} oracle_stats;
+
+/* One full step (forces+collisions, drift+commit, stable compaction) on a host block laid out as the
+ * reference does (src/nbody.cu:66-77): [P vec2f[N] | V vec2f[N] | M f32[N] | R f32[N]], 24*N bytes.
+ * *n becomes the survivor count and the block is re-carved for it.
+ *   absorb_pairs : optional int32[2*absorb_cap], receives E_t as (i,j) in i-major, visit-order-minor order
+ *   deleted      : optional int32[deleted_cap], receives D_t ascending
+ *   pre_compaction : optional 24*N bytes, the block after the drift and before compaction
+ * Returns 0, or -1 on bad arguments. */
+int oracle_step_f32(void* block, int* n, float dt, int fieldW, int fieldH, float growth, int semantics,
+                    int32_t* absorb_pairs, int absorb_cap, int32_t* deleted, int deleted_cap,
+                    oracle_stats* stats, void* pre_compaction);
+
+/* fp64 twin on [P vec2[N] | V vec2[N] | M f64[N] | R f64[N]], 48*N bytes (include/vec2.h layout). */
+int oracle_step_f64(void* block, int* n, double dt, int fieldW, int fieldH, double growth, int semantics,
+                    int32_t* absorb_pairs, int absorb_cap, int32_t* deleted, int deleted_cap,
+                    oracle_stats* stats, void* pre_compaction);
+
+/* Range form used for sharded tests and for the bounded cpu_baseline sample: computes the post-drift state
+ * of bodies [lo,hi) from the step-start block WITHOUT modifying it and without compaction.
+ * outP/outV are vec2 arrays of (hi-lo), outM/outR scalars of (hi-lo); del_flags (optional) uint8 of (hi-lo). */
+int oracle_range_f32(const void* block, int n, int lo, int hi, float dt, int fieldW, int fieldH,
+                     float growth, int semantics, float* outP, float* outV, float* outM, float* outR,
+                     uint8_t* del_flags, oracle_stats* stats);
+int oracle_range_f64(const void* block, int n, int lo, int hi, double dt, int fieldW, int fieldH,
+                     double growth, int semantics, double* outP, double* outV, double* outM, double* outR,
+                     uint8_t* del_flags, oracle_stats* stats);
+
+/* Number of ordered pairs the stepper evaluates in one step at body count n. */
+int64_t oracle_pairs_per_step(int n, int semantics);
+
+/* J(i) enumeration for tests of the quirk mask: writes the visit-ordered j list of body i, returns its
+ * length (or -1 if i is inactive). out must hold n entries. */
+int oracle_jlist(int n, int i, int semantics, int32_t* out);
+
+void oracle_set_threads(int nthreads);   /* 0 = OpenMP default */
+int oracle_get_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
