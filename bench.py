@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- body-pair-interactions/sec of the HIP stepper (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (forces + collisions + drift + compaction [+ slot all-gather]) over the
+whole body set.  Workload = BASELINE.json configs[3] shape: N=262144 bodies, fp32, the reference's own initial
+condition (seed 1024), radii 0 (the "positions-only exchange" headline row of SURVEY.md 8d), literal
+reference semantics.  N>1: STRONG scaling - the same 262144 bodies range-partitioned over the ranks, one
+process per GPU, the per-step all-gather over RCCL inside the library; torch.distributed (gloo) only carries
+the 128-byte communicator id, the barriers and the max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region starts.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 20.0            # SURVEY.md 8d convention (18 + sqrt + divide)
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (packed issue)
+PEAK_FP64_VALU_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
+    """Times the CPU oracle (oracle/nbody_oracle.c, OpenMP over i) on a bounded sample of the same workload:
+    a contiguous range of i-bodies of step 1, every one against all its j's.  Checker used as the reported
+    baseline only (kind 'port': the reference has no CPU stepper)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    n = bodies.numBodies
+    threads = ol.port().oracle_get_max_threads()
+    blk = bodies.contiguousData
+    dt, gr = np.float32(cfg.timestep), np.float32(cfg.growthRate)
+    if bodies.precision == nb.F64:
+        dt, gr = float(dt), float(gr)
+    probe = min(n, 4 * threads)
+    t0 = time.perf_counter()
+    *_, st = ol.port_range(blk, n, 0, probe, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    t_probe = time.perf_counter() - t0
+    rate = st.pairs / max(t_probe, 1e-9)
+    per_body = st.pairs / probe
+    count = int(max(threads * 4, min(n, budget_s * rate / per_body)))
+    count = min(n, count - count % threads if count > threads else count)
+    lo = (n // 2 // 128) * 128
+    lo = min(lo, n - count)
+    t0 = time.perf_counter()
+    *_, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    t = time.perf_counter() - t0
+    return {"value": st.pairs / t, "unit": "body-pair-interactions/sec", "cores": threads, "kind": "port",
+            "sample": "bodies [%d,%d) of step 1 at N=%d against all j (%d pairs, %.1f s, OpenMP %d threads)" %
+                      (lo, lo + count, n, st.pairs, t, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bodies", type=int, default=262144)
+    ap.add_argument("--stock-radii", action="store_true", help="radii 50-200 (collisions on) instead of 0")
+    ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--variant", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+
+    import torch                       # plumbing: rendezvous, barriers, device selection
+    import ppa_nbody_collisions_amd as nb
+
+    comm_id = None
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        torch.cuda.set_device(local_rank)
+        box = [nb.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+    else:
+        torch.cuda.set_device(local_rank)
+
+    precision = nb.F64 if a.fp64 else nb.F32
+    kw = {} if a.stock_radii else {"minRadius": 0.0, "maxRadius": 0.0}
+    cfg = nb.stock_config(particleCount=a.bodies, totalIterations=a.steps, **kw)
+    bodies = nb.init_bodies(cfg, precision)
+    st = nb.Stepper(cfg, precision=precision, device=local_rank, rank=rank, world=world, comm_id=comm_id,
+                    kernel_variant=a.variant)
+    st.upload(bodies)
+
+    def barrier():
+        torch.cuda.synchronize()
+        st.sync()
+        if dist is not None:
+            dist.barrier()
+
+    st.step(a.warmup)
+    barrier()
+    s0 = st.stats()
+    st.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    st.step(a.steps)
+    st.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    s1 = st.stats()
+    st.set_kernel_timing(False)
+
+    pairs = s1.pairs - s0.pairs
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+        p = torch.tensor([pairs], dtype=torch.int64)
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        pairs = int(p[0])
+
+    if rank == 0:
+        value = pairs / elapsed
+        launches = max(1, s1.force_kernel_launches)
+        k_ms = s1.force_kernel_ms / launches                  # HIP events on the launch stream
+        k_pairs = (s1.pairs - s0.pairs) / launches            # pairs one launch of THIS rank evaluates
+        real = 8 if a.fp64 else 4
+        alg_bytes = 12.0 * real * (s1.n_own if world > 1 else s1.n_bodies) + 4.0 * real * s1.n_bodies
+        # compulsory bytes of one launch: read the {x,y,m,r} replica once (4 reals/body) + read V and write
+        # the staged record and V of the own range (2 + 4 + 2 reals/body); world=1: 48*N fp32 = SURVEY.md 8d
+        peak_valu = PEAK_FP64_VALU_TFLOPS if a.fp64 else PEAK_FP32_VALU_TFLOPS
+        out = {
+            "metric": "body-pair-interactions/sec at N=%d" % a.bodies,
+            "value": value, "unit": "body-pair-interactions/sec", "n_gpus": a.gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64" if a.fp64 else "f32",
+            "data": "synthetic",
+            "config": {"workload": "N=%d bodies, %s, %s, reference initial condition (seed 1024), literal "
+                                   "reference step semantics, %d steps" %
+                                   (a.bodies, "fp64" if a.fp64 else "fp32",
+                                    "stock radii 50-200 (collisions on)" if a.stock_radii else "radii 0",
+                                    a.steps),
+                       "bodies_after": s1.n_bodies,
+                       "parallelism": "range-partition x%d, RCCL slot all-gather per step" % world
+                       if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                         "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                         "traffic": None, "kernel": "forces", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline_valu": {"bound": "valu_fp32" if not a.fp64 else "valu_fp64",
+                              "achieved": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12, "peak": peak_valu,
+                              "unit": "TFLOP/s",
+                              "frac": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12 / peak_valu,
+                              "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": k_pairs},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
+        print(json.dumps(out), flush=True)
+    st.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

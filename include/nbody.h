@@ -1,0 +1,228 @@
+/* include/nbody.h -- C ABI of the MI355X-native direct N-body gravity + collision stepper.
+ *
+ * Drop-in boundary for the hot path of Aidan900/ppa-nbody-collisions.  The reference has no plugin / FFI
+ * layer: main() (src/nbody.cu:373-551) calls its kernels directly.  Each entry point below names the
+ * reference code it replaces (paths are relative to the reference tree).  Plain C types only; no
+ * exceptions, no exit(): every function returns an nbody_status (0 = OK, negative = error) and
+ * nbody_last_error_string() describes the last failure on the calling thread.
+ *
+ * Library: ppa-nbody-collisions_amd/libnbody_mi355x.so (built by __graft_entry__.build() / csrc/Makefile).
+ * All compute entry points need a gfx950 device and FAIL (NBODY_ERR_NO_DEVICE / NBODY_ERR_HIP) without one:
+ * there is no CPU fallback anywhere in the library.
+ */
+#ifndef NBODY_MI355X_H
+#define NBODY_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_ABI_VERSION 1
+
+/* ---------------------------------------------------------------------------------------------------
+ * Status codes
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum nbody_status {
+    NBODY_OK = 0,
+    NBODY_ERR_INVALID = -1,      /* bad argument                                                       */
+    NBODY_ERR_IO = -2,           /* config file cannot be opened  (include/nbodyConfig.h:25-28)        */
+    NBODY_ERR_PARSE = -3,        /* "<key> invalid value"          (include/nbodyConfig.h:41-45 etc.)  */
+    NBODY_ERR_NOMEM = -4,        /* host or device allocation failed (src/nbody.cu:68-72)              */
+    NBODY_ERR_NO_DEVICE = -5,    /* no gfx950 device visible                                           */
+    NBODY_ERR_HIP = -6,          /* a HIP runtime call failed (replaces CUDA_SYNC_CHECK, :20-33)       */
+    NBODY_ERR_CAPACITY = -7,     /* more bodies / events than the context was created for             */
+    NBODY_ERR_COMM = -8,         /* RCCL failure or collective library unavailable                     */
+    NBODY_ERR_STATE = -9         /* call sequence error (e.g. step before upload)                      */
+} nbody_status;
+
+const char* nbody_last_error_string(void);
+const char* nbody_status_string(int status);
+int nbody_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Body layout -- include/vec2f.h:13-20 (Vec2f: 8 bytes, align 4) and include/vec2.h:6-17 (Vec2<double>).
+ * A host "block" is ONE allocation [Positions vec2[N] | Velocities vec2[N] | Masses real[N] | Radii real[N]]
+ * exactly as BodiesData::alloc carves it (src/nbody.cu:63-79): 24*N bytes (fp32) or 48*N bytes (fp64).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct nbody_vec2f { float X, Y; } nbody_vec2f;
+typedef struct nbody_vec2 { double X, Y; } nbody_vec2;
+
+typedef enum nbody_precision { NBODY_F32 = 0, NBODY_F64 = 1 } nbody_precision;
+
+size_t nbody_block_bytes(int n, int precision);
+/* BodiesData::alloc (src/nbody.cu:63-79) / freeData (:81-86), host part. */
+void* nbody_block_alloc(int n, int precision);
+void nbody_block_free(void* block);
+/* Pointer carving of src/nbody.cu:74-77 (and :147-150, :283-286). Any output pointer may be NULL. */
+int nbody_block_carve_f32(void* block, int n, nbody_vec2f** P, nbody_vec2f** V, float** M, float** R);
+int nbody_block_carve_f64(void* block, int n, nbody_vec2** P, nbody_vec2** V, double** M, double** R);
+/* Stable compaction on `mass != 0` with re-carving for the new count (src/nbody.cu:488-510). Host side
+ * utility for callers that step through the reference-shaped launches below. Returns the new count or <0. */
+int nbody_block_compact(void* block, int n, int precision);
+
+/* ---------------------------------------------------------------------------------------------------
+ * nbodyConfig.txt -- include/nbodyConfig.h:4-19 (struct ConfigData) and :22-227 (parseConfigFile)
+ * ------------------------------------------------------------------------------------------------- */
+#define NBODY_IMAGE_PATH_MAX 1024
+
+enum { /* bit k of nbody_config.present is set when key k was accepted */
+    NBODY_KEY_particleCount = 0, NBODY_KEY_totalIterations, NBODY_KEY_save_Image_Every_Xth_Iteration,
+    NBODY_KEY_timestep, NBODY_KEY_minRandBodyMass, NBODY_KEY_maxRandBodyMass, NBODY_KEY_minRadius,
+    NBODY_KEY_maxRadius, NBODY_KEY_radiusGrowthRate, NBODY_KEY_imgWidth, NBODY_KEY_imgHeight,
+    NBODY_KEY_fieldWidth, NBODY_KEY_fieldHeight, NBODY_KEY_imagePath, NBODY_KEY_COUNT
+};
+
+typedef struct nbody_config {
+    int particleCount;
+    int totalIterations;
+    int save_Image_Every_Xth_Iteration;
+    float timestep;
+    float minRandBodyMass;
+    float maxRandBodyMass;
+    float minRadius;
+    float maxRadius;
+    float growthRate;               /* file key "radiusGrowthRate" (include/nbodyConfig.h:13,208-220) */
+    int imgWidth;
+    int imgHeight;
+    int fieldWidth;
+    int fieldHeight;
+    char imagePath[NBODY_IMAGE_PATH_MAX];
+    uint32_t present;               /* deviation: the reference leaves missing keys uninitialised;  */
+                                    /* we zero them and record which keys were seen                 */
+} nbody_config;
+
+/* parseConfigFile (include/nbodyConfig.h:22-227): same grammar (`key=value` per line, std::stoi/std::stof
+ * number syntax so `0.2f`, `1e4f`, `50.f` parse), same echo text on stdout including the reference's
+ * `minRandBodymass=` / `growthRate=` spellings and `Invalid variable: <name>` for unknown lines.  Instead of
+ * exit(1) it returns NBODY_ERR_IO / NBODY_ERR_PARSE after printing the reference's message. */
+int nbody_config_parse(const char* path, nbody_config* out);
+/* Same, echo written to file descriptor echo_fd (-1: no echo). */
+int nbody_config_parse_fd(const char* path, nbody_config* out, int echo_fd);
+/* The stock nbodyConfig.txt values (nbodyConfig.txt:1-14). */
+void nbody_config_stock(nbody_config* out);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Initial conditions -- src/nbody.cu:401-416 with jbutil::randgen (include/jbutil.h:514-562)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct nbody_rng { uint64_t u, v, w; } nbody_rng;
+void nbody_rng_seed(nbody_rng* g, uint64_t s);            /* randgen::seed   jbutil.h:525-534 */
+uint64_t nbody_rng_ival64(nbody_rng* g);                  /* randgen::ival64 jbutil.h:545-552 */
+double nbody_rng_fval(nbody_rng* g);                      /* randgen::fval() jbutil.h:553-556 */
+double nbody_rng_fval_range(nbody_rng* g, double a, double b); /* fval(a,b)  jbutil.h:557-560 */
+
+/* Fills a block of cfg->particleCount bodies: seed 1024, draws x,y,m,r per body in that order, v = 0.
+ * fp32 rounds each draw to float exactly where the reference does; fp64 keeps the double draws. */
+int nbody_init_bodies(const nbody_config* cfg, void* block, int precision);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stepper context -- replaces the per-iteration host loop src/nbody.cu:460-545 (cudaMalloc scratch,
+ * H2D, ComputeForces, MoveBodies, D2H, host compaction) with device-resident state.
+ * ------------------------------------------------------------------------------------------------- */
+typedef enum nbody_semantics {
+    NBODY_LITERAL = 0,  /* exactly what src/nbody.cu computes, index quirks included */
+    NBODY_CLEAN = 1     /* every body active, true all-pairs, j ascending                                */
+} nbody_semantics;
+
+enum { /* nbody_ctx_desc.flags */
+    NBODY_FLAG_RECORD_EVENTS = 1u << 0,   /* keep the collision event log (E_t, D_t of SURVEY.md A.2)   */
+    NBODY_FLAG_GROUP_EXCHANGE = 1u << 1   /* world>1, every rank is a context of this process: the       */
+                                          /* exchange is done by nbody_group_step with peer copies        */
+};
+
+typedef struct nbody_ctx nbody_ctx;
+
+typedef struct nbody_ctx_desc {
+    int precision;          /* nbody_precision                                                          */
+    int semantics;          /* nbody_semantics                                                          */
+    int capacity;           /* max bodies (>= first upload's n)                                         */
+    int device;             /* HIP device ordinal                                                       */
+    int rank, world;        /* range partition of bodies over ranks; world = 1 for a single GPU         */
+    uint32_t flags;
+    int event_capacity;     /* max logged events (0: default)                                           */
+    double timestep;        /* cfg.timestep  (kernel arg `timestep`,  src/nbody.cu:482)                 */
+    double growthRate;      /* cfg.growthRate (kernel arg `growthRate`, :482)                           */
+    int fieldWidth;         /* kernel args :482                                                         */
+    int fieldHeight;
+    const void* comm_id;    /* world>1 with RCCL: 128-byte id from nbody_comm_unique_id on rank 0       */
+    int kernel_variant;     /* 0 = default; see DESIGN.md (tuning / A-B testing only)                   */
+} nbody_ctx_desc;
+
+void nbody_ctx_desc_from_config(nbody_ctx_desc* d, const nbody_config* cfg, int precision);
+
+int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* desc);
+int nbody_ctx_destroy(nbody_ctx* ctx);
+
+/* BodiesData::uploadToDevice (src/nbody.cu:88-96): copies a host block of n bodies (the FULL set on every
+ * rank) to the device; the context keeps it resident between steps. */
+int nbody_upload(nbody_ctx* ctx, const void* block, int n);
+/* nsteps iterations of the loop body src/nbody.cu:463-510 (forces+collisions, drift+commit, stable
+ * compaction), asynchronous: returns after enqueueing. */
+int nbody_step(nbody_ctx* ctx, int nsteps);
+/* cudaMemcpyAsync D2H of the state (src/nbody.cu:486) + the survivors' re-carved block (:496-510):
+ * writes 24*n (48*n) bytes laid out for the CURRENT count n and stores n. block must hold `capacity`. */
+int nbody_download(nbody_ctx* ctx, void* block, int* n);
+int nbody_body_count(nbody_ctx* ctx, int* n);   /* synchronises */
+int nbody_sync(nbody_ctx* ctx);                 /* CUDA_SYNC_CHECK (src/nbody.cu:20-33,546)           */
+
+typedef struct nbody_event {  /* one collision event, in the index space of the step it happened in    */
+    int32_t step;             /* step counter since upload (0-based)                                   */
+    int32_t i;                /* the body whose thread saw the collision                               */
+    int32_t j;                /* the other body; j < 0 is never produced                               */
+    int32_t kind;             /* 0: i absorbs j (E_t)   1: i deleted because of j (D_t witness)        */
+} nbody_event;
+/* Copies up to cap logged events (unordered within a step) and the total number logged since the last
+ * clear; total > cap means the caller's buffer was too small, total > event_capacity means the log
+ * overflowed (extra events were counted, not stored). */
+int nbody_get_events(nbody_ctx* ctx, nbody_event* out, int cap, int64_t* total);
+int nbody_clear_events(nbody_ctx* ctx);
+
+typedef struct nbody_stats {
+    int64_t steps;            /* steps enqueued since upload                                           */
+    int64_t pairs;            /* ordered (i,j) pairs evaluated by THIS rank since upload (device count) */
+    double force_kernel_ms;   /* sum of force-kernel durations measured with HIP events (0 if off)      */
+    int64_t force_kernel_launches;
+    int n_bodies;             /* current global body count                                             */
+    int n_own;                /* bodies owned by this rank                                             */
+} nbody_stats;
+int nbody_get_stats(nbody_ctx* ctx, nbody_stats* out);  /* synchronises */
+/* Bracket every force-kernel launch with HIP events on the context's stream (bench / profiling). */
+int nbody_set_kernel_timing(nbody_ctx* ctx, int enable);
+
+/* Multi-rank plumbing (world > 1).  One process per GPU; the host language moves the 128-byte id. */
+#define NBODY_COMM_ID_BYTES 128
+int nbody_comm_unique_id(void* out128);   /* ncclGetUniqueId via dlopen("librccl.so.1") */
+
+/* Single-process form of the same partition: ctxs[g] is rank g of `world`, all created in this process
+ * with NBODY_FLAG_GROUP_EXCHANGE (one per device, or several on one device).  The per-step all-gather is
+ * done with stream-ordered device-to-device copies; no RCCL, no host synchronisation inside the loop. */
+int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps);
+int nbody_group_download(nbody_ctx** ctxs, int world, void* block, int* n);
+/* Global index range [lo, lo+cnt) currently owned by this rank (synchronises). */
+int nbody_own_range(nbody_ctx* ctx, int* lo, int* cnt);
+void* nbody_ctx_stream(nbody_ctx* ctx);   /* hipStream_t of the context */
+
+/* ---------------------------------------------------------------------------------------------------
+ * Reference-shaped launches on caller-owned DEVICE memory: one-to-one replacements of the two <<<>>> sites
+ * src/nbody.cu:481-483.  d_bodyData is a device block in the reference layout for numBodies bodies;
+ * velocities are updated in place, updatedMasses/updatedRadii are the scratch arrays of :463-464.  The
+ * never-allocated `updatedVelocities` argument of the reference (:441) is dropped.  `stream` is a
+ * hipStream_t (NULL = default stream).  numBlocks follows :473; pass nbody_num_blocks(numBodies).
+ * ------------------------------------------------------------------------------------------------- */
+int nbody_num_blocks(int numBodies);      /* src/nbody.cu:473 */
+int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updatedMasses, float* d_updatedRadii,
+                                    int numBodies, float timestep, int fieldWidth, int fieldHeight,
+                                    int numBlocks, float growthRate, void* stream);
+int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updatedMasses, const float* d_updatedRadii,
+                                 int numBodies, float timestep, int numBlocks, void* stream);
+
+/* Device self-test used by the GPU test-suite: exhaustively compares the kernel's fp32 sqrt and reciprocal
+ * against fp64-then-round on all 2^32 inputs; *mismatches receives {sqrt, rcp} mismatch counts. */
+int nbody_selftest_ieee_f32(int device, uint64_t mismatches[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_MI355X_H */

@@ -1,0 +1,660 @@
+// csrc/nbody_ctx.hip -- host side of the stepper context behind the C ABI (include/nbody.h).
+//
+// Replaces the reference's per-iteration host loop (src/nbody.cu:460-545: cudaMalloc scratch, H2D of the
+// whole state, two launches, D2H of the whole state, O(N) host compaction, cudaFree) with device-resident
+// state: per step three stream-ordered phases and no host synchronisation,
+//     compute : forces+collisions+drift of the own range  -> staged records (step-t index space)
+//               stable compaction of the own range        -> this rank's send slot {count, survivors}
+//     exchange: all-gather of the slots over RCCL/xGMI (world > 1 only)
+//     commit  : gathered slots -> replica of step t+1, new {N, lo, cnt} published on the device
+// Global stable order is rank order, so the reference's index-dependent semantics survive
+// sharding unchanged.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "nbody.h"
+#include "nbody_error.h"
+#include "nbody_kernels.hpp"
+
+using namespace nbk;
+
+#define HIP_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess)                                                                            \
+            return nbody_fail(NBODY_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),      \
+                              __FILE__, __LINE__);                                                        \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL through dlopen: no link-time dependency, and inside a process that already loaded a librccl.so.1
+// (PyTorch ships one) the same copy is reused.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Id128 { char b[NBODY_COMM_ID_BYTES]; };   // ncclUniqueId, passed by value
+
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return NBODY_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) {
+        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return nbody_fail(NBODY_ERR_COMM, "cannot dlopen librccl.so.1: %s", dlerror());
+    Rccl r;
+    r.lib = lib;
+    r.GetUniqueId = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(lib, "ncclCommInitRank");
+    r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+    r.CommDestroy = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
+        return nbody_fail(NBODY_ERR_COMM, "librccl is missing a required symbol");
+    g_rccl = r;
+    return NBODY_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                    \
+    do {                                                                                                  \
+        int r__ = (expr);                                                                                 \
+        if (r__ != 0)                                                                                     \
+            return nbody_fail(NBODY_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r__));        \
+    } while (0)
+
+constexpr int kNcclInt8 = 0;   // ncclInt8 / ncclChar
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+struct nbody_ctx {
+    nbody_ctx_desc desc{};
+    size_t real_bytes = 4;      // sizeof(T)
+    size_t rec_bytes = 16;      // sizeof(Rec<T>)
+    int cap = 0;                // global capacity
+    int cap_own = 0;            // own-range capacity
+    hipStream_t stream = nullptr;
+    // device memory
+    void* J = nullptr;          // Rec<T>[cap]
+    void* Vown = nullptr;       // Vec2<T>[cap_own]
+    void* S_J = nullptr;        // Rec<T>[cap_own]
+    void* S_V = nullptr;        // Vec2<T>[cap_own]
+    unsigned char* slot = nullptr;    // SlotHeader + Rec<T>[cap_own]          (send slot)
+    unsigned char* gather = nullptr;  // world * slot_bytes                    (== slot when world == 1)
+    size_t slot_bytes = 0;
+    int* blk_counts = nullptr;
+    Meta* meta = nullptr;
+    Counters* counters = nullptr;
+    Event* events = nullptr;
+    int ev_cap = 0;
+    // host mirrors / staging
+    void* h_stage = nullptr;    // pinned, max(cap*rec, cap*2*real ...)
+    size_t h_stage_bytes = 0;
+    Meta* h_meta = nullptr;     // pinned
+    Counters* h_counters = nullptr;
+    int n_upper = 0;            // host-side upper bound of the global count (exact after a sync)
+    int own_upper = 0;          // upper bound of the own count
+    int lo_known = 0;           // own range start as of the last sync (lower bound drifts down only)
+    bool uploaded = false;
+    int64_t steps = 0;
+    // RCCL
+    void* comm = nullptr;
+    // kernel timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;   // pairs (start, stop) not yet resolved
+    double force_ms = 0.0;
+    int64_t force_launches = 0;
+};
+
+namespace {
+
+template <typename T>
+StepParams<T> make_params(const nbody_ctx_desc& d) {
+    StepParams<T> p;
+    p.dt = (T)d.timestep;            // cfg values are floats; double holds them exactly
+    p.growth = (T)d.growthRate;
+    p.G = (T)6.67408e-11f;           // src/nbody.cu:37, float literal (widened for fp64: SURVEY.md H6)
+    p.wall_hi_x = (T)d.fieldWidth;
+    p.wall_lo_x = (T)(-d.fieldWidth);
+    p.wall_hi_y = (T)d.fieldHeight;
+    p.wall_lo_y = (T)(-d.fieldHeight);
+    p.literal = d.semantics == NBODY_LITERAL;
+    return p;
+}
+
+int resolve_timing(nbody_ctx* c) {
+    for (size_t k = 0; k + 1 < c->ev_pool.size(); k += 2) {
+        float ms = 0.f;
+        HIP_TRY(hipEventSynchronize(c->ev_pool[k + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k], c->ev_pool[k + 1]));
+        c->force_ms += ms;
+        c->force_launches += 1;
+        hipEventDestroy(c->ev_pool[k]);
+        hipEventDestroy(c->ev_pool[k + 1]);
+    }
+    c->ev_pool.clear();
+    return NBODY_OK;
+}
+
+int read_meta(nbody_ctx* c) {
+    HIP_TRY(hipMemcpyAsync(c->h_meta, c->meta, sizeof(Meta), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_upper = c->h_meta->n;
+    c->own_upper = c->h_meta->cnt;
+    c->lo_known = c->h_meta->lo;
+    return NBODY_OK;
+}
+
+template <typename T>
+int launch_compute(nbody_ctx* c) {
+    const StepParams<T> p = make_params<T>(c->desc);
+    // Workgroups cover every reference block that can intersect the own range: a range of cnt bodies
+    // touches at most cnt/128 + 2 blocks wherever it starts.  The count only shrinks between syncs, so the
+    // host-side upper bound is safe; the kernel takes the exact range from the device-side Meta and
+    // workgroups past it exit at once.
+    const int nblocks = c->own_upper / kTile + 2;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, c->stream));
+    }
+    const bool log = (c->desc.flags & NBODY_FLAG_RECORD_EVENTS) != 0;
+    if (log) {
+        hipLaunchKernelGGL((forces_v1<T, true>), dim3(nblocks), dim3(kTile), 0, c->stream,
+                           (const Rec<T>*)c->J, (const Vec2<T>*)c->Vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V,
+                           (const Meta*)c->meta, p, c->events, c->ev_cap, c->counters);
+    } else {
+        hipLaunchKernelGGL((forces_v1<T, false>), dim3(nblocks), dim3(kTile), 0, c->stream,
+                           (const Rec<T>*)c->J, (const Vec2<T>*)c->Vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V,
+                           (const Meta*)c->meta, p, c->events, c->ev_cap, c->counters);
+    }
+    HIP_TRY(hipGetLastError());
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        c->ev_pool.push_back(e0);
+        c->ev_pool.push_back(e1);
+    }
+    const int nblk = (c->own_upper + kCompactBlock - 1) / kCompactBlock > 0
+                         ? (c->own_upper + kCompactBlock - 1) / kCompactBlock : 1;
+    hipLaunchKernelGGL((compact_count<T>), dim3(nblk), dim3(kCompactBlock), 0, c->stream,
+                       (const Rec<T>*)c->S_J, (const Meta*)c->meta, c->blk_counts);
+    hipLaunchKernelGGL((compact_scatter<T>), dim3(nblk), dim3(kCompactBlock), 0, c->stream,
+                       (const Rec<T>*)c->S_J, (const Vec2<T>*)c->S_V, (const Meta*)c->meta,
+                       (const int*)c->blk_counts, nblk, (SlotHeader*)c->slot,
+                       (Rec<T>*)(c->slot + sizeof(SlotHeader)), (Vec2<T>*)c->Vown);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+template <typename T>
+int launch_commit(nbody_ctx* c) {
+    const int gx = (c->own_upper + 255) / 256 > 0 ? (c->own_upper + 255) / 256 : 1;
+    // every rank's slot can hold up to cap_own survivors; own_upper bounds only OUR count, so size the
+    // grid by the largest count any rank can have
+    const int gx_all = c->desc.world > 1 ? (c->cap_own + 255) / 256 : gx;
+    hipLaunchKernelGGL((unpack_slots<T>), dim3(gx_all, c->desc.world), dim3(256), 0, c->stream,
+                       (const unsigned char*)c->gather, c->slot_bytes, c->desc.world, c->desc.rank,
+                       (Rec<T>*)c->J, c->meta);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int do_exchange(nbody_ctx* c) {
+    if (c->desc.world == 1) return NBODY_OK;     // gather aliases slot
+    if (!c->comm) return nbody_fail(NBODY_ERR_STATE, "context has no communicator");
+    RCCL_TRY(g_rccl.AllGather(c->slot, c->gather, c->slot_bytes, kNcclInt8, c->comm, c->stream));
+    return NBODY_OK;
+}
+
+int compute_phase(nbody_ctx* c) {
+    return c->desc.precision == NBODY_F64 ? launch_compute<double>(c) : launch_compute<float>(c);
+}
+int commit_phase(nbody_ctx* c) {
+    int rc = c->desc.precision == NBODY_F64 ? launch_commit<double>(c) : launch_commit<float>(c);
+    if (rc == NBODY_OK) c->steps += 1;
+    return rc;
+}
+
+void free_all(nbody_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->desc.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
+    if (c->gather && c->gather != c->slot) hipFree(c->gather);
+    hipFree(c->slot);
+    hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->counters); hipFree(c->events);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_meta) hipHostFree(c->h_meta);
+    if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int nbody_comm_unique_id(void* out128) {
+    if (!out128) return nbody_fail(NBODY_ERR_INVALID, "nbody_comm_unique_id: NULL");
+    int rc = rccl_load();
+    if (rc != NBODY_OK) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(out128));
+    return NBODY_OK;
+}
+
+int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
+    if (!out || !d) return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: NULL argument");
+    *out = nullptr;
+    if (d->capacity <= 0 || d->world < 1 || d->rank < 0 || d->rank >= d->world)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad capacity/rank/world");
+    if (d->precision != NBODY_F32 && d->precision != NBODY_F64)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad precision");
+    if (d->semantics != NBODY_LITERAL)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: only NBODY_LITERAL semantics is built yet");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return nbody_fail(NBODY_ERR_NO_DEVICE, "no HIP device visible (%s); this library has no CPU path",
+                          e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (d->device < 0 || d->device >= ndev)
+        return nbody_fail(NBODY_ERR_INVALID, "device ordinal %d out of range (0..%d)", d->device, ndev - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return nbody_fail(NBODY_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 only", d->device,
+                          prop.gcnArchName);
+    HIP_TRY(hipSetDevice(d->device));
+
+    nbody_ctx* c = new (std::nothrow) nbody_ctx();
+    if (!c) return nbody_fail(NBODY_ERR_NOMEM, "nbody_ctx_create: out of host memory");
+    c->desc = *d;
+    c->desc.comm_id = nullptr;
+    c->real_bytes = d->precision == NBODY_F64 ? 8 : 4;
+    c->rec_bytes = 4 * c->real_bytes;
+    c->cap = d->capacity;
+    c->cap_own = (int)(((long long)d->capacity + d->world - 1) / d->world) + 1;
+    c->ev_cap = d->event_capacity > 0 ? d->event_capacity : (1 << 20);
+    c->slot_bytes = sizeof(SlotHeader) + (size_t)c->cap_own * c->rec_bytes;
+    c->slot_bytes = (c->slot_bytes + 255) & ~(size_t)255;
+
+#define CTX_TRY(expr)                                                                                     \
+    do {                                                                                                  \
+        hipError_t e__ = (expr);                                                                          \
+        if (e__ != hipSuccess) {                                                                          \
+            int rc__ = nbody_fail(e__ == hipErrorOutOfMemory ? NBODY_ERR_NOMEM : NBODY_ERR_HIP,           \
+                                  "%s failed: %s", #expr, hipGetErrorString(e__));                        \
+            free_all(c);                                                                                  \
+            return rc__;                                                                                  \
+        }                                                                                                 \
+    } while (0)
+
+    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CTX_TRY(hipMalloc(&c->J, (size_t)c->cap * c->rec_bytes));
+    CTX_TRY(hipMalloc(&c->Vown, (size_t)c->cap_own * 2 * c->real_bytes));
+    CTX_TRY(hipMalloc(&c->S_J, (size_t)c->cap_own * c->rec_bytes));
+    CTX_TRY(hipMalloc(&c->S_V, (size_t)c->cap_own * 2 * c->real_bytes));
+    CTX_TRY(hipMalloc((void**)&c->slot, c->slot_bytes));
+    if (d->world > 1) CTX_TRY(hipMalloc((void**)&c->gather, c->slot_bytes * d->world));
+    else c->gather = c->slot;
+    CTX_TRY(hipMalloc((void**)&c->blk_counts, sizeof(int) * (size_t)(c->cap_own / kCompactBlock + 2)));
+    CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
+    CTX_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
+    CTX_TRY(hipMalloc((void**)&c->events, sizeof(Event) * (size_t)c->ev_cap));
+    CTX_TRY(hipMemset(c->counters, 0, sizeof(Counters)));
+    CTX_TRY(hipMemset(c->meta, 0, sizeof(Meta)));
+    c->h_stage_bytes = (size_t)c->cap * c->rec_bytes;
+    CTX_TRY(hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc((void**)&c->h_meta, sizeof(Meta), hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
+#undef CTX_TRY
+
+    if (d->world > 1 && !(d->flags & NBODY_FLAG_GROUP_EXCHANGE)) {
+        int rc = rccl_load();
+        if (rc == NBODY_OK && !d->comm_id)
+            rc = nbody_fail(NBODY_ERR_INVALID, "world > 1 needs comm_id (nbody_comm_unique_id on rank 0)");
+        if (rc == NBODY_OK) {
+            Id128 id;
+            memcpy(id.b, d->comm_id, sizeof(id.b));
+            int r = g_rccl.CommInitRank(&c->comm, d->world, id, d->rank);
+            if (r != 0) rc = nbody_fail(NBODY_ERR_COMM, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
+        }
+        if (rc != NBODY_OK) { free_all(c); return rc; }
+    }
+    *out = c;
+    return NBODY_OK;
+}
+
+int nbody_ctx_destroy(nbody_ctx* ctx) {
+    free_all(ctx);
+    return NBODY_OK;
+}
+
+void* nbody_ctx_stream(nbody_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int nbody_upload(nbody_ctx* c, const void* block, int n) {
+    if (!c || !block || n < 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_upload: bad argument");
+    if (n > c->cap) return nbody_fail(NBODY_ERR_CAPACITY, "nbody_upload: %d bodies > capacity %d", n, c->cap);
+    HIP_TRY(hipSetDevice(c->desc.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int G = c->desc.world, g = c->desc.rank;
+    const int lo = (int)((long long)n * g / G), hi = (int)((long long)n * (g + 1) / G);
+    const int cnt = hi - lo;
+    if (cnt > c->cap_own) return nbody_fail(NBODY_ERR_CAPACITY, "own range %d > own capacity %d", cnt, c->cap_own);
+    // pack [P|V|M|R] (src/nbody.cu:66-77) into {x,y,m,r} records
+    if (c->desc.precision == NBODY_F64) {
+        const double* P = (const double*)block;
+        const double* V = P + 2 * (size_t)n;
+        const double* M = V + 2 * (size_t)n;
+        const double* R = M + (size_t)n;
+        Rec<double>* st = (Rec<double>*)c->h_stage;
+        for (int i = 0; i < n; ++i) st[i] = Rec<double>{P[2 * i], P[2 * i + 1], M[i], R[i]};
+        HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<double>), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 16, hipMemcpyHostToDevice, c->stream));
+    } else {
+        const float* P = (const float*)block;
+        const float* V = P + 2 * (size_t)n;
+        const float* M = V + 2 * (size_t)n;
+        const float* R = M + (size_t)n;
+        Rec<float>* st = (Rec<float>*)c->h_stage;
+        for (int i = 0; i < n; ++i) st[i] = Rec<float>{P[2 * i], P[2 * i + 1], M[i], R[i]};
+        HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<float>), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    c->h_meta->n = n; c->h_meta->lo = lo; c->h_meta->cnt = cnt; c->h_meta->step = 0;
+    HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_upper = n; c->own_upper = cnt; c->lo_known = lo;
+    c->uploaded = true;
+    c->steps = 0;
+    c->force_ms = 0; c->force_launches = 0;
+    return NBODY_OK;
+}
+
+// Single-process multi-context stepping: every rank of the partition is a context of THIS process (one per
+// device, or several on one device for tests).  The per-step exchange is done with stream-ordered
+// device-to-device copies and events, no host synchronisation and no RCCL.
+int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
+    if (!ctxs || world < 1 || nsteps < 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_group_step: bad argument");
+    for (int g = 0; g < world; ++g) {
+        nbody_ctx* c = ctxs[g];
+        if (!c || c->desc.world != world || c->desc.rank != g || !c->uploaded)
+            return nbody_fail(NBODY_ERR_STATE, "nbody_group_step: context %d is not rank %d of %d (or not uploaded)", g, g, world);
+        if (world > 1 && !(c->desc.flags & NBODY_FLAG_GROUP_EXCHANGE))
+            return nbody_fail(NBODY_ERR_STATE, "nbody_group_step: context %d lacks NBODY_FLAG_GROUP_EXCHANGE", g);
+    }
+    std::vector<hipEvent_t> ready(world), done(world);
+    for (int g = 0; g < world; ++g) {
+        HIP_TRY(hipSetDevice(ctxs[g]->desc.device));
+        HIP_TRY(hipEventCreateWithFlags(&ready[g], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&done[g], hipEventDisableTiming));
+    }
+    int rc = NBODY_OK;
+    for (int s = 0; s < nsteps && rc == NBODY_OK; ++s) {
+        for (int g = 0; g < world && rc == NBODY_OK; ++g) {
+            nbody_ctx* c = ctxs[g];
+            HIP_TRY(hipSetDevice(c->desc.device));
+            // the slot of rank g may be rewritten only after every rank has copied it out (previous step)
+            if (s > 0) for (int h = 0; h < world; ++h) if (h != g) HIP_TRY(hipStreamWaitEvent(c->stream, done[h], 0));
+            rc = compute_phase(c);
+            if (rc == NBODY_OK) HIP_TRY(hipEventRecord(ready[g], c->stream));
+        }
+        for (int h = 0; h < world && rc == NBODY_OK; ++h) {
+            nbody_ctx* c = ctxs[h];
+            HIP_TRY(hipSetDevice(c->desc.device));
+            if (world > 1) {
+                for (int g = 0; g < world; ++g) {
+                    if (g != h) HIP_TRY(hipStreamWaitEvent(c->stream, ready[g], 0));
+                    HIP_TRY(hipMemcpyAsync(c->gather + (size_t)g * c->slot_bytes, ctxs[g]->slot, c->slot_bytes,
+                                           hipMemcpyDeviceToDevice, c->stream));
+                }
+                HIP_TRY(hipEventRecord(done[h], c->stream));
+            }
+            rc = commit_phase(c);
+        }
+    }
+    for (int g = 0; g < world; ++g) {
+        hipSetDevice(ctxs[g]->desc.device);
+        hipStreamSynchronize(ctxs[g]->stream);
+        hipEventDestroy(ready[g]);
+        hipEventDestroy(done[g]);
+    }
+    return rc;
+}
+
+// Full state of a single-process group: replica of rank 0 plus every rank's own velocities.
+int nbody_group_download(nbody_ctx** ctxs, int world, void* block, int* n_out) {
+    if (!ctxs || world < 1 || !block || !n_out) return nbody_fail(NBODY_ERR_INVALID, "nbody_group_download: bad argument");
+    int rc = nbody_download(ctxs[0], block, n_out);
+    if (rc != NBODY_OK) return rc;
+    const int n = *n_out;
+    const size_t rb = ctxs[0]->real_bytes;
+    unsigned char* V = (unsigned char*)block + 2 * rb * (size_t)n;
+    for (int g = 1; g < world; ++g) {
+        nbody_ctx* c = ctxs[g];
+        HIP_TRY(hipSetDevice(c->desc.device));
+        rc = read_meta(c);
+        if (rc != NBODY_OK) return rc;
+        if (c->h_meta->n != n) return nbody_fail(NBODY_ERR_STATE, "group ranks disagree on the body count");
+        HIP_TRY(hipMemcpyAsync(V + 2 * rb * (size_t)c->h_meta->lo, c->Vown, (size_t)c->h_meta->cnt * 2 * rb,
+                               hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return NBODY_OK;
+}
+
+int nbody_step(nbody_ctx* c, int nsteps) {
+    if (!c || nsteps < 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_step: bad argument");
+    if (!c->uploaded) return nbody_fail(NBODY_ERR_STATE, "nbody_step before nbody_upload");
+    if (c->desc.world > 1 && (c->desc.flags & NBODY_FLAG_GROUP_EXCHANGE))
+        return nbody_fail(NBODY_ERR_STATE, "group context: step it with nbody_group_step");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    for (int s = 0; s < nsteps; ++s) {
+        int rc = compute_phase(c);
+        if (rc != NBODY_OK) return rc;
+        rc = do_exchange(c);
+        if (rc != NBODY_OK) return rc;
+        rc = commit_phase(c);
+        if (rc != NBODY_OK) return rc;
+    }
+    return NBODY_OK;
+}
+
+int nbody_sync(nbody_ctx* c) {
+    if (!c) return nbody_fail(NBODY_ERR_INVALID, "NULL context");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_body_count(nbody_ctx* c, int* n) {
+    if (!c || !n) return nbody_fail(NBODY_ERR_INVALID, "nbody_body_count: NULL");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    int rc = read_meta(c);
+    if (rc != NBODY_OK) return rc;
+    *n = c->h_meta->n;
+    return NBODY_OK;
+}
+
+int nbody_own_range(nbody_ctx* c, int* lo, int* cnt) {
+    if (!c || !lo || !cnt) return nbody_fail(NBODY_ERR_INVALID, "nbody_own_range: NULL");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    int rc = read_meta(c);
+    if (rc != NBODY_OK) return rc;
+    *lo = c->h_meta->lo;
+    *cnt = c->h_meta->cnt;
+    return NBODY_OK;
+}
+
+int nbody_download(nbody_ctx* c, void* block, int* n_out) {
+    if (!c || !block || !n_out) return nbody_fail(NBODY_ERR_INVALID, "nbody_download: NULL argument");
+    if (!c->uploaded) return nbody_fail(NBODY_ERR_STATE, "nbody_download before nbody_upload");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    int rc = read_meta(c);
+    if (rc != NBODY_OK) return rc;
+    const int n = c->h_meta->n, lo = c->h_meta->lo, cnt = c->h_meta->cnt;
+    const size_t rb = c->real_bytes;
+    HIP_TRY(hipMemcpyAsync(c->h_stage, c->J, (size_t)n * c->rec_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned char* P = (unsigned char*)block;
+    unsigned char* V = P + 2 * rb * (size_t)n;
+    unsigned char* M = V + 2 * rb * (size_t)n;
+    unsigned char* R = M + rb * (size_t)n;
+    const unsigned char* st = (const unsigned char*)c->h_stage;
+    for (int i = 0; i < n; ++i) {
+        memcpy(P + 2 * rb * i, st + c->rec_bytes * i, 2 * rb);
+        memcpy(M + rb * i, st + c->rec_bytes * i + 2 * rb, rb);
+        memcpy(R + rb * i, st + c->rec_bytes * i + 3 * rb, rb);
+    }
+    // velocities: own range from this rank; other ranks' through the slot machinery (padded all-gather)
+    if (c->desc.world == 1) {
+        HIP_TRY(hipMemcpyAsync(V, c->Vown, (size_t)cnt * 2 * rb, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else if (c->comm) {
+        // reuse S_V (cap_own entries) as the send buffer and S_J/gather as the receive area is too small
+        // for vec2 of all ranks in fp64 only if rec_bytes < 2*real_bytes, which never holds (4 vs 2 reals)
+        RCCL_TRY(g_rccl.AllGather(c->Vown, c->gather, (size_t)c->cap_own * 2 * rb, kNcclInt8, c->comm,
+                                  c->stream));
+        std::vector<int> counts(c->desc.world);
+        // counts are in the last exchanged slot headers only after a step; recompute from Meta instead:
+        // every rank's lo is the prefix of counts, gathered via a tiny second all-gather of Meta
+        Meta* d_all = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_all, sizeof(Meta) * c->desc.world));
+        RCCL_TRY(g_rccl.AllGather(c->meta, d_all, sizeof(Meta), kNcclInt8, c->comm, c->stream));
+        std::vector<Meta> h_all(c->desc.world);
+        HIP_TRY(hipMemcpyAsync(h_all.data(), d_all, sizeof(Meta) * c->desc.world, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        hipFree(d_all);
+        for (int g = 0; g < c->desc.world; ++g) {
+            HIP_TRY(hipMemcpy(V + 2 * rb * (size_t)h_all[g].lo,
+                              c->gather + (size_t)g * c->cap_own * 2 * rb, (size_t)h_all[g].cnt * 2 * rb,
+                              hipMemcpyDeviceToHost));
+        }
+    } else {
+        // group context: only the own range lives here; nbody_group_download assembles the rest
+        memset(V, 0, 2 * rb * (size_t)n);
+        HIP_TRY(hipMemcpyAsync(V + 2 * rb * (size_t)lo, c->Vown, (size_t)cnt * 2 * rb, hipMemcpyDeviceToHost,
+                               c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    *n_out = n;
+    return NBODY_OK;
+}
+
+int nbody_get_events(nbody_ctx* c, nbody_event* out, int cap, int64_t* total) {
+    if (!c || !total || cap < 0 || (cap > 0 && !out)) return nbody_fail(NBODY_ERR_INVALID, "nbody_get_events: bad argument");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const unsigned long long tot = c->h_counters->events;
+    *total = (int64_t)tot;
+    unsigned long long ncopy = tot;
+    if (ncopy > (unsigned long long)c->ev_cap) ncopy = c->ev_cap;
+    if (ncopy > (unsigned long long)cap) ncopy = cap;
+    static_assert(sizeof(nbody_event) == sizeof(Event), "event layouts must match");
+    if (ncopy) HIP_TRY(hipMemcpy(out, c->events, ncopy * sizeof(Event), hipMemcpyDeviceToHost));
+    return NBODY_OK;
+}
+
+int nbody_clear_events(nbody_ctx* c) {
+    if (!c) return nbody_fail(NBODY_ERR_INVALID, "NULL context");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    HIP_TRY(hipMemsetAsync(&c->counters->events, 0, sizeof(unsigned long long), c->stream));
+    return NBODY_OK;
+}
+
+int nbody_set_kernel_timing(nbody_ctx* c, int enable) {
+    if (!c) return nbody_fail(NBODY_ERR_INVALID, "NULL context");
+    c->timing = enable != 0;
+    return NBODY_OK;
+}
+
+int nbody_get_stats(nbody_ctx* c, nbody_stats* out) {
+    if (!c || !out) return nbody_fail(NBODY_ERR_INVALID, "nbody_get_stats: NULL");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    int rc = read_meta(c);
+    if (rc != NBODY_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = resolve_timing(c);
+    if (rc != NBODY_OK) return rc;
+    out->steps = c->steps;
+    out->pairs = (int64_t)c->h_counters->pairs;
+    out->force_kernel_ms = c->force_ms;
+    out->force_kernel_launches = c->force_launches;
+    out->n_bodies = c->h_meta->n;
+    out->n_own = c->h_meta->cnt;
+    return NBODY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reference-shaped launches (src/nbody.cu:481-483)
+// ---------------------------------------------------------------------------------------------------------
+int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_updR, int numBodies,
+                                    float timestep, int fieldWidth, int fieldHeight, int numBlocks,
+                                    float growthRate, void* stream) {
+    if (!d_bodyData || !d_updM || !d_updR || numBodies <= 0 || numBlocks <= 0)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_launch_compute_forces_f32: bad argument");
+    nbody_ctx_desc d{};
+    d.timestep = timestep; d.growthRate = growthRate; d.fieldWidth = fieldWidth; d.fieldHeight = fieldHeight;
+    d.semantics = NBODY_LITERAL;
+    const StepParams<float> p = make_params<float>(d);
+    hipLaunchKernelGGL(ref_layout_forces_f32, dim3(numBlocks), dim3(kTile), 0, (hipStream_t)stream, d_bodyData,
+                       d_updM, d_updR, numBodies, numBlocks, p);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const float* d_updR, int numBodies,
+                                 float timestep, int numBlocks, void* stream) {
+    if (!d_bodyData || !d_updM || !d_updR || numBodies <= 0 || numBlocks <= 0)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_launch_move_bodies_f32: bad argument");
+    hipLaunchKernelGGL(ref_layout_move_f32, dim3(numBlocks), dim3(kTile), 0, (hipStream_t)stream, d_bodyData,
+                       d_updM, d_updR, numBodies, timestep);
+    HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_selftest_ieee_f32(int device, uint64_t mismatches[2]) {
+    if (!mismatches) return nbody_fail(NBODY_ERR_INVALID, "nbody_selftest_ieee_f32: NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return nbody_fail(NBODY_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(selftest_ieee_f32, dim3(256 * 16), dim3(256), 0, 0, d);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(d);
+    mismatches[0] = h[0];
+    mismatches[1] = h[1];
+    return NBODY_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,439 @@
+// csrc/nbody_kernels.hpp -- gfx950 (CDNA4, MI355X) device code of the stepper.
+//
+// What is computed is fixed by the reference (src/nbody.cu:126-292 of the reference);
+// how it is computed is not: nothing here follows the reference's kernel structure.
+//
+//   * Bodies live on the device as 16-byte (fp32) / 32-byte (fp64) records {x, y, m, r}: one vector load
+//     per body when a tile is staged, one ds_read_b128 per pair in the hot loop.
+//   * The force/collision kernel keeps the reference's per-body ACCUMULATION ORDER (tile k of block b holds
+//     the cyclic bodies 128(b+k)..+127 mod N; lane t walks a tile as (t+off) mod L) because fp32 sums are
+//     order-sensitive beyond the 1e-5 budget: with IEEE sqrt/divide and no contraction the
+//     results are bit-identical to the CPU oracle.  The rotated walk is a conflict-free LDS pattern on
+//     CDNA4: the 64 lanes of a wave read 64 consecutive 16-byte records.
+//   * The drift (MoveBodies) is fused into the force kernel's epilogue; results go to a staging array in
+//     step-t index space, a stable on-device compaction then builds step t+1 (no host round trip).
+//
+// All floating-point statements are written one rounding per operation and the file is compiled with
+// -ffp-contract=off; `#pragma clang fp contract(off)` below makes that independent of the command line.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#pragma clang fp contract(off)
+
+namespace nbk {
+
+constexpr int kTile = 128;          // bodies per reference block / tile (THREADS_PER_BLOCK, src/nbody.cu:36)
+constexpr int kWave = 64;
+
+template <typename T> struct Rec;   // {x, y, m, r}
+template <> struct alignas(16) Rec<float> { float x, y, m, r; };
+template <> struct alignas(32) Rec<double> { double x, y, m, r; };
+template <typename T> struct alignas(2 * sizeof(T)) Vec2 { T x, y; };
+
+// Step-resident scalars, device memory.  Written by the unpack kernel, read by everything else.
+struct Meta {
+    int n;        // global body count N_t
+    int lo;       // first global index owned by this rank
+    int cnt;      // number of bodies owned by this rank
+    int step;     // step counter since upload
+};
+
+struct Event { int32_t step, i, j, kind; };
+
+struct Counters {
+    unsigned long long pairs;     // ordered pairs evaluated (this rank)
+    unsigned long long events;    // events logged (may exceed capacity: overflow is counted, not stored)
+};
+
+// Send slot of one rank for the per-step exchange: header + compacted survivors of the own range.
+struct SlotHeader {
+    int count;
+    int pad[7];
+};
+static_assert(sizeof(SlotHeader) == 32, "slot header is 32 bytes so fp64 records stay 32-byte aligned");
+
+template <typename T>
+struct StepParams {
+    T dt;
+    T growth;
+    T G;
+    T wall_hi_x, wall_lo_x;   // (T)fieldWidth, (T)(-fieldWidth): the int->real conversions of :256-257
+    T wall_hi_y, wall_lo_y;
+    int literal;              // 1: reference index semantics, 0: clean all-pairs
+};
+
+template <typename T> __device__ __forceinline__ T ieee_sqrt(T x);
+template <> __device__ __forceinline__ float ieee_sqrt<float>(float x) { return __builtin_sqrtf(x); }
+template <> __device__ __forceinline__ double ieee_sqrt<double>(double x) { return __builtin_sqrt(x); }
+
+// ---------------------------------------------------------------------------------------------------------
+// One (i, j) interaction, SURVEY.md A.1 step 2 (src/nbody.cu:210-239, include/vec2f.h:45-93).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct BodyAcc {
+    T xi, yi, mi, ri;      // start-of-step snapshot (:169-171)
+    T fx, fy;              // force accumulator (:153)
+    T mnew, rnew;          // :174-175
+    int deleted;           // :180
+};
+
+template <typename T, bool kLog>
+__device__ __forceinline__ void interact(BodyAcc<T>& a, const Rec<T>& bj, T growth, int i, int j,
+                                         Event* ev, int ev_cap, Counters* ctr, int step) {
+    // :129-133 areParticlesColliding
+    const T dx = bj.x - a.xi;
+    const T dy = bj.y - a.yi;
+    const T d2 = (dx * dx) + (dy * dy);
+    const T rs = a.ri + bj.r;
+    const bool hit = d2 <= rs * rs;
+    const bool ge = a.mi >= bj.m;
+    const bool lt = a.mi < bj.m;
+    if (__builtin_expect(hit && (ge || lt), 0)) {
+        if (ge) {                       // :215-221
+            a.mnew = a.mnew + bj.m;
+            a.rnew = a.rnew + bj.r * growth;
+        } else {                        // :222-226
+            a.deleted = 1;
+        }
+        if (kLog) {
+            const unsigned long long slot = atomicAdd(&ctr->events, 1ull);
+            if (slot < (unsigned long long)ev_cap) ev[slot] = Event{step, i, j, ge ? 0 : 1};
+        }
+        return;
+    }
+    // :230-239 (a NaN mass with hit falls through to here, as in the reference's if / else-if)
+    const T d = ieee_sqrt<T>(d2);       // same operands, same rounding as the recomputation at :232
+    const T c = (d * d) * d;
+    const T inv = (T)1.0f / c;          // vec2f.h:52
+    const T mx = bj.m * dx;             // vec2f.h:45-47
+    const T my = bj.m * dy;
+    a.fx = a.fx + inv * mx;             // vec2f.h:52, :83-85
+    a.fy = a.fy + inv * my;
+}
+
+// Epilogue of one active body: SURVEY.md A.1 steps 3-7 (src/nbody.cu:245-264 and MoveBodies :288-290).
+template <typename T>
+__device__ __forceinline__ void finish_body(const BodyAcc<T>& a, Vec2<T> v, const StepParams<T>& p,
+                                            Rec<T>& out, Vec2<T>& vout) {
+    const T um = a.deleted ? (T)0 : a.mnew;                      // :245
+    const T ur = a.rnew;                                         // :246
+    const T ax = p.G * a.fx, ay = p.G * a.fy;                    // :250
+    const T dvx = p.dt * ax, dvy = p.dt * ay;                    // :252
+    const T tx = a.xi + (ax * p.dt), ty = a.yi + (ay * p.dt);    // :256-260
+    if (tx > p.wall_hi_x - a.ri || tx < p.wall_lo_x + a.ri) v.x = v.x * (T)(-1);
+    if (ty > p.wall_hi_y - a.ri || ty < p.wall_lo_y + a.ri) v.y = v.y * (T)(-1);
+    v.x = v.x + dvx;                                             // :264
+    v.y = v.y + dvy;
+    vout = v;
+    out.x = a.xi + p.dt * v.x;                                   // :288
+    out.y = a.yi + p.dt * v.y;
+    out.m = um;                                                  // :289
+    out.r = ur;                                                  // :290
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Force + collision + drift kernel, variant "v1": 128-lane workgroup = one reference block, one body per
+// lane, tiles double-buffered in LDS (one barrier per tile).
+//
+//   J        replica of all bodies, global index space of step t
+//   Vown     velocities of the own range, local index q = i - lo
+//   S_J,S_V  staged post-step state of the own range (still step-t index space, before compaction)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, bool kLog>
+__global__ __launch_bounds__(kTile) void forces_v1(const Rec<T>* __restrict__ J,
+                                                   const Vec2<T>* __restrict__ Vown,
+                                                   Rec<T>* __restrict__ S_J, Vec2<T>* __restrict__ S_V,
+                                                   const Meta* __restrict__ meta, StepParams<T> p,
+                                                   Event* ev, int ev_cap, Counters* ctr) {
+    __shared__ Rec<T> tile[2][kTile];
+    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    const int t = threadIdx.x;
+    const int b = lo / kTile + blockIdx.x;                 // reference block index
+    const long long blk0 = (long long)b * kTile;
+    if (blk0 >= (long long)lo + cnt) return;               // grid is sized for the capacity; whole-WG exit
+    const int i = (int)blk0 + t;
+    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
+    const bool mine = i >= lo && i < lo + cnt;
+    // literal: only bodies with a thread are updated (quirk Q2); N < 128: the single block is guarded by i < N
+    const bool active = mine && i < N && (long long)i < (long long)nb * kTile;
+    const bool loader = i < N || N >= kTile;               // N < 128: lanes >= N load nothing (:143)
+
+    BodyAcc<T> a;
+    Vec2<T> v{0, 0};
+    if (mine) {
+        const Rec<T> me = J[i];
+        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
+        v = Vown[i - lo];
+    } else {
+        a.xi = a.yi = a.mi = a.ri = 0;
+    }
+    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
+    unsigned long long pairs = 0;
+
+    // prologue: tile 0
+    {
+        long long src = blk0 + t;                          // (i + 128*0) % N
+        if (src >= N) src %= N;
+        if (loader) tile[0][t] = J[src];
+    }
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        const int cur = k & 1;
+        // prefetch tile k+1 into registers while tile k is consumed
+        Rec<T> nxt;
+        const bool have_next = (k + 1 < nb);
+        if (have_next && loader) {
+            long long src = blk0 + (long long)kTile * (k + 1) + t;    // :186
+            if (src >= N) src %= N;
+            nxt = J[src];
+        }
+        const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;        // :194 (quirk Q1)
+        if (active) {
+            const long long base = blk0 + (long long)kTile * k;
+            if (L == kTile) {
+                for (int off = (k == 0 ? 1 : 0); off < kTile; ++off) {   // :200-204 skip (k=0, off=0)
+                    const int s = (t + off) & (kTile - 1);                // :207
+                    long long j = base + s;
+                    if (j >= N) j %= N;
+                    interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+                }
+                pairs += (k == 0) ? kTile - 1 : kTile;
+            } else {
+                for (int off = (k == 0 ? 1 : 0); off < L; ++off) {
+                    const int s = (t + off) % L;
+                    long long j = base + s;
+                    if (j >= N) j %= N;
+                    interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+                }
+                pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+            }
+        }
+        if (have_next && loader) tile[cur ^ 1][t] = nxt;
+        __syncthreads();
+    }
+
+    if (mine) {
+        const int q = i - lo;
+        if (active) {
+            Rec<T> out; Vec2<T> vout;
+            finish_body<T>(a, v, p, out, vout);
+            S_J[q] = out;
+            S_V[q] = vout;
+        } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
+            S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
+            S_V[q] = v;
+        }
+    }
+    // one atomic per wave for the pair counter
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
+    if ((t & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stable compaction of the own range on `mass != 0` (src/nbody.cu:488-510), two small kernels.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kCompactBlock = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(kCompactBlock) void compact_count(const Rec<T>* __restrict__ S_J,
+                                                               const Meta* __restrict__ meta,
+                                                               int* __restrict__ blk_counts) {
+    __shared__ int wsum[kCompactBlock / kWave];
+    const int cnt = meta->cnt;
+    const int q = blockIdx.x * kCompactBlock + threadIdx.x;
+    const bool keep = q < cnt && S_J[q].m != (T)0;
+    const unsigned long long bal = __ballot(keep);
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < kCompactBlock / kWave; ++w) s += wsum[w];
+        blk_counts[blockIdx.x] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kCompactBlock) void compact_scatter(const Rec<T>* __restrict__ S_J,
+                                                                 const Vec2<T>* __restrict__ S_V,
+                                                                 const Meta* __restrict__ meta,
+                                                                 const int* __restrict__ blk_counts, int nblk,
+                                                                 SlotHeader* __restrict__ slot_hdr,
+                                                                 Rec<T>* __restrict__ slot_recs,
+                                                                 Vec2<T>* __restrict__ Vown) {
+    __shared__ int wsum[kCompactBlock / kWave];
+    __shared__ int red[kCompactBlock / kWave];
+    __shared__ int base_s;
+    const int cnt = meta->cnt;
+    // offset of this block = sum of the counts of all lower blocks
+    int part = 0;
+    for (int bidx = threadIdx.x; bidx < (int)blockIdx.x; bidx += kCompactBlock) part += blk_counts[bidx];
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) part += __shfl_down(part, sh, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = part;
+
+    const int q = blockIdx.x * kCompactBlock + threadIdx.x;
+    Rec<T> rec{};
+    Vec2<T> vel{};
+    bool keep = false;
+    if (q < cnt) {
+        rec = S_J[q];
+        vel = S_V[q];
+        keep = rec.m != (T)0;
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = threadIdx.x / kWave;
+    if (lane == 0) wsum[wid] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < kCompactBlock / kWave; ++w) s += red[w];
+        base_s = s;
+        if ((int)blockIdx.x == nblk - 1) {
+            int tot = s;
+            for (int w = 0; w < kCompactBlock / kWave; ++w) tot += wsum[w];
+            slot_hdr->count = tot;
+        }
+    }
+    __syncthreads();
+    if (keep) {
+        int off = base_s;
+        for (int w = 0; w < wid; ++w) off += wsum[w];
+        off += __popcll(bal & ((1ull << lane) - 1ull));
+        slot_recs[off] = rec;
+        Vown[off] = vel;
+    }
+}
+
+// Builds the step t+1 replica from the gathered slots of all ranks (global stable order = rank order) and
+// publishes the new Meta.  grid = (ceil(cap_own / 256), world).
+template <typename T>
+__global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restrict__ gather, size_t slot_bytes,
+                                                    int world, int rank, Rec<T>* __restrict__ J,
+                                                    Meta* __restrict__ meta) {
+    const int g = blockIdx.y;
+    int off = 0, total = 0, mine_off = 0, mine_cnt = 0;
+    for (int h = 0; h < world; ++h) {
+        const int c = reinterpret_cast<const SlotHeader*>(gather + (size_t)h * slot_bytes)->count;
+        if (h < g) off += c;
+        if (h < rank) mine_off += c;
+        if (h == rank) mine_cnt = c;
+        total += c;
+    }
+    const unsigned char* slot = gather + (size_t)g * slot_bytes;
+    const int c = reinterpret_cast<const SlotHeader*>(slot)->count;
+    const Rec<T>* recs = reinterpret_cast<const Rec<T>*>(slot + sizeof(SlotHeader));
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < c) J[off + q] = recs[q];
+    if (g == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        // every block has read meta-independent data only, so the in-place update is race-free
+        const int step = meta->step;
+        meta->n = total;
+        meta->lo = mine_off;
+        meta->cnt = mine_cnt;
+        meta->step = step + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reference-shaped kernels on the reference's device block layout (drop-in for the <<<>>> sites
+// src/nbody.cu:481-483): velocities updated in place, updatedMasses / updatedRadii scratch written.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTile) void ref_layout_forces_f32(void* bodyData, float* __restrict__ updM,
+                                                               float* __restrict__ updR, int N, int nb,
+                                                               StepParams<float> p) {
+    __shared__ Rec<float> tile[2][kTile];
+    const Vec2<float>* P = reinterpret_cast<const Vec2<float>*>(bodyData);    // :147-150
+    Vec2<float>* V = reinterpret_cast<Vec2<float>*>(bodyData) + N;
+    const float* M = reinterpret_cast<const float*>(V + N);
+    const float* R = M + N;
+    const int t = threadIdx.x;
+    const long long blk0 = (long long)blockIdx.x * kTile;
+    const int i = (int)blk0 + t;
+    const bool active = i < N;                                                // :143
+    BodyAcc<float> a;
+    Vec2<float> v{0, 0};
+    if (active) {
+        const Vec2<float> pi = P[i];
+        a.xi = pi.x; a.yi = pi.y; a.mi = M[i]; a.ri = R[i];
+        v = V[i];
+    } else {
+        a.xi = a.yi = a.mi = a.ri = 0;
+    }
+    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
+    auto load = [&](int k) -> Rec<float> {
+        long long src = blk0 + (long long)kTile * k + t;
+        if (src >= N) src %= N;
+        const Vec2<float> pj = P[src];
+        return Rec<float>{pj.x, pj.y, M[src], R[src]};
+    };
+    if (active) tile[0][t] = load(0);
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        const int cur = k & 1;
+        Rec<float> nxt{};
+        const bool have_next = k + 1 < nb;
+        if (have_next && active) nxt = load(k + 1);
+        const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;
+        if (active) {
+            for (int off = (k == 0 ? 1 : 0); off < L; ++off) {
+                const int s = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L);
+                interact<float, false>(a, tile[cur][s], p.growth, i, 0, nullptr, 0, nullptr, 0);
+            }
+        }
+        if (have_next && active) tile[cur ^ 1][t] = nxt;
+        __syncthreads();
+    }
+    if (active) {
+        // finish_body computes the drifted position too; only the :245-264 part is stored here, the drift
+        // belongs to the separate MoveBodies launch in this API shape
+        Rec<float> out; Vec2<float> vout;
+        finish_body<float>(a, v, p, out, vout);
+        updM[i] = out.m;
+        updR[i] = out.r;
+        V[i] = vout;
+    }
+}
+
+__global__ __launch_bounds__(kTile) void ref_layout_move_f32(void* bodyData, const float* __restrict__ updM,
+                                                             const float* __restrict__ updR, int N, float dt) {
+    Vec2<float>* P = reinterpret_cast<Vec2<float>*>(bodyData);                // :283-286
+    const Vec2<float>* V = P + N;
+    float* M = reinterpret_cast<float*>(P + 2 * (size_t)N);
+    float* R = M + N;
+    const int j = blockIdx.x * kTile + threadIdx.x;
+    if (j < N) {
+        Vec2<float> pj = P[j];
+        const Vec2<float> vj = V[j];
+        pj.x = pj.x + dt * vj.x;                                              // :288
+        pj.y = pj.y + dt * vj.y;
+        P[j] = pj;
+        M[j] = updM[j];                                                       // :289
+        R[j] = updR[j];                                                       // :290
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device self-test: fp32 sqrt and reciprocal as compiled in this TU vs fp64 evaluation rounded once to fp32
+// (innocuous double rounding: 53 >= 2*24+2), on all 2^32 bit patterns.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void selftest_ieee_f32(unsigned long long* mism) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    unsigned long long bad_sqrt = 0, bad_rcp = 0;
+    for (unsigned long long u = gid; u < (1ull << 32); u += stride) {
+        const float x = __uint_as_float((unsigned)u);
+        const float s1 = ieee_sqrt<float>(x);
+        const float s2 = (float)__builtin_sqrt((double)x);
+        const float r1 = 1.0f / x;
+        const float r2 = (float)(1.0 / (double)x);
+        const bool s_ok = (__float_as_uint(s1) == __float_as_uint(s2)) || (s1 != s1 && s2 != s2);
+        const bool r_ok = (__float_as_uint(r1) == __float_as_uint(r2)) || (r1 != r1 && r2 != r2);
+        bad_sqrt += !s_ok;
+        bad_rcp += !r_ok;
+    }
+    if (bad_sqrt) atomicAdd(&mism[0], bad_sqrt);
+    if (bad_rcp) atomicAdd(&mism[1], bad_rcp);
+}
+
+}  // namespace nbk

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs oracle/_ref/libnbody_ref.so (built where /root/reference exists)")
+
+
+def _gpu_present():
+    # device files only: importing torch / touching HIP here would initialise the GPU in the test runner
+    return os.path.exists("/dev/kfd") and os.path.isdir("/dev/dri")
+
+
+def pytest_collection_modifyitems(config, items):
+    import oracle_lib
+    skip_ref = pytest.mark.skip(reason="oracle/_ref/libnbody_ref.so not built (no /root/reference here)")
+    skip_gpu = pytest.mark.skip(reason="no GPU device files on this host")
+    for item in items:
+        if "ref" in item.keywords and not oracle_lib.have_ref():
+            item.add_marker(skip_ref)
+        if "gpu" in item.keywords and not _gpu_present():
+            item.add_marker(skip_gpu)
+
+
+@pytest.fixture(scope="session")
+def nb():
+    """The product package (ctypes over libnbody_mi355x.so). Import fails loudly if the library is absent."""
+    import ppa_nbody_collisions_amd as m
+    return m

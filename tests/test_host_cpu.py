@@ -1,0 +1,155 @@
+"""CPU tests of the product's HOST code (C: config reader, generator, body container) through the C ABI, and
+of the ABI surface itself.  No compute entry point is called here: those need a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CASES = json.load(open(os.path.join(GOLD, "config_cases.json")))
+
+
+def _parse_with_echo(nb, path):
+    r, w = os.pipe()
+    cfg = nb.ConfigData()
+    rc = nb.lib.nbody_config_parse_fd(os.fsencode(path), ctypes.byref(cfg), w)
+    os.close(w)
+    echo = b""
+    while True:
+        chunk = os.read(r, 65536)
+        if not chunk:
+            break
+        echo += chunk
+    os.close(r)
+    return rc, cfg, echo.decode("latin-1")
+
+
+@pytest.mark.parametrize("name", sorted(k for k in CASES if not k.startswith("__")))
+def test_config_matches_reference_parser(nb, tmp_path, name):
+    case = CASES[name]
+    p = tmp_path / "nbodyConfig.txt"
+    p.write_bytes(case["text"].encode("latin-1"))
+    rc, cfg, echo = _parse_with_echo(nb, str(p))
+    assert echo == case["echo"]
+    if case["exit"] != 0:                       # the reference calls exit(1) here (nbodyConfig.h:41-45 ...)
+        assert rc == -3 and "invalid value" in nb.lib.nbody_last_error_string().decode()
+        return
+    assert rc == 0
+    for key, want in case["values"].items():
+        field = "growthRate" if key == "radiusGrowthRate" else key
+        got = getattr(cfg, field)
+        if isinstance(want, str) and key != "imagePath":
+            assert "%08x" % np.float32(got).view(np.uint32) == want, key
+        else:
+            assert got == want, key
+        assert cfg.has(key)
+    for key in nb.KEYS:
+        if key not in case["values"]:
+            assert not cfg.has(key)
+
+
+def test_config_missing_file(nb):
+    rc, cfg, echo = _parse_with_echo(nb, "/nonexistent/nbodyConfig.txt")
+    assert rc == -2 and echo == CASES["__missing_file__"]["echo"]
+
+
+def test_config_write_roundtrip(nb, tmp_path):
+    cfg = nb.stock_config(particleCount=262144, totalIterations=1000, minRadius=0.0, maxRadius=0.0)
+    p = str(tmp_path / "nbodyConfig.txt")
+    nb.write_config(p, cfg)
+    back = nb.parseConfigFile(p, echo=False)
+    for f, _ in nb.ConfigData._fields_:
+        if f not in ("_imagePath", "present"):
+            assert getattr(back, f) == getattr(cfg, f), f
+    assert back.imagePath == "iter_img"
+
+
+def test_rng_kat(nb):
+    kat = json.load(open(os.path.join(GOLD, "rng_kat.json")))
+    for seed, e in kat.items():
+        g = nb.Rng()
+        nb.lib.nbody_rng_seed(ctypes.byref(g), int(seed))
+        assert ["%016x" % nb.lib.nbody_rng_ival64(ctypes.byref(g)) for _ in range(8)] == e["ival64"]
+        nb.lib.nbody_rng_seed(ctypes.byref(g), int(seed))
+        got = [np.float64(nb.lib.nbody_rng_fval_range(ctypes.byref(g), -3.5, 1e17)).view(np.uint64)
+               for _ in range(8)]
+        assert ["%016x" % int(x) for x in got] == e["fval_m3p5_1e17_bits"]
+    # SURVEY.md B.2
+    assert kat["1024"]["ival64"][0] == "ec7cc99017775737"
+
+
+def test_init_bodies_matches_reference(nb):
+    z = np.load(os.path.join(GOLD, "init_stock.npz"))
+    b = nb.init_bodies(nb.stock_config(particleCount=64))
+    assert np.array_equal(b.block.view(np.uint32), z["stock_n64"])
+    cfg = nb.stock_config(particleCount=48, fieldWidth=5000, fieldHeight=7000, minRandBodyMass=1.0,
+                          maxRandBodyMass=1e6, minRadius=0.0, maxRadius=0.0)
+    assert np.array_equal(nb.init_bodies(cfg).block.view(np.uint32), z["small_n48"])
+    # draws do not depend on N: body k always consumes draws 4k..4k+3
+    big = nb.init_bodies(nb.stock_config(particleCount=1000))
+    assert np.array_equal(big.Positions[:64].view(np.uint32), b.Positions.view(np.uint32))
+    # fp64 keeps the unrounded draws; rounding them to fp32 gives the fp32 initial condition
+    b64 = nb.init_bodies(nb.stock_config(particleCount=64), nb.F64)
+    assert np.array_equal(b64.block.astype(np.float32).view(np.uint32), z["stock_n64"])
+
+
+def test_block_layout_and_compaction(nb):
+    assert nb.lib.nbody_block_bytes(1000, nb.F32) == 24000 and nb.lib.nbody_block_bytes(1000, nb.F64) == 48000
+    n = 10
+    b = nb.BodiesData(n)
+    b.contiguousData[:] = np.arange(6 * n, dtype=np.float32) + 1
+    ptrs = [ctypes.c_void_p() for _ in range(4)]
+    assert nb.lib.nbody_block_carve_f32(b.ptr, n, *[ctypes.byref(p) for p in ptrs]) == 0
+    base = b.ptr
+    assert [p.value - base for p in ptrs] == [0, 8 * n, 16 * n, 20 * n]          # src/nbody.cu:74-77
+    b.Masses[[2, 5, 9]] = 0.0
+    want = [np.delete(a, [2, 5, 9], axis=0).copy() for a in (b.Positions, b.Velocities, b.Masses, b.Radii)]
+    newn = nb.lib.nbody_block_compact(b.ptr, n, nb.F32)
+    assert newn == 7
+    b.numBodies = newn
+    for got, w in zip((b.Positions, b.Velocities, b.Masses, b.Radii), want):
+        assert np.array_equal(got, w)
+
+
+def test_library_exports_every_declared_symbol(nb):
+    hdr = open(os.path.join(ROOT, "include", "nbody.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nbody_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"nbody_status"}
+    assert len(declared) >= 35
+    raw = ctypes.CDLL(nb.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), "library does not export %s" % name
+        assert name in nb.SYMBOLS, "python binding does not cover %s" % name
+    assert set(nb.SYMBOLS) == declared
+    assert nb.lib.nbody_abi_version() == 1
+
+
+def test_compute_fails_loudly_without_gpu(nb):
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(nb.NbodyError) as ei:
+        nb.Stepper(nb.stock_config(particleCount=128))
+    assert ei.value.status == -5
+    m = (ctypes.c_uint64 * 2)()
+    assert nb.lib.nbody_selftest_ieee_f32(0, ctypes.byref(m)) == -5
+
+
+def test_product_does_not_touch_the_oracle(nb):
+    """The product package must not import, link or load anything under oracle/ (no CPU fallback)."""
+    pkg = os.path.join(ROOT, "ppa-nbody-collisions_amd")
+    needles = ("oracle/", "libnbody_oracle", "libnbody_ref", "oracle_lib", "nbody_oracle", "oracle_step",
+               "oracle_range")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hpp", ".hip", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                for needle in needles:
+                    assert needle not in txt, (os.path.join(dirpath, f), needle)
+    blob = open(nb.LIB_PATH, "rb").read()
+    for needle in (b"libnbody_oracle", b"libnbody_ref", b"oracle_step"):
+        assert needle not in blob

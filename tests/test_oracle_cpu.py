@@ -1,0 +1,137 @@
+"""CPU tests of the checker itself: the C restatement (oracle/nbody_oracle.c) against the golden vectors that
+were generated from the reference's own kernel text (tests/golden/make_golden.py), and - where the literal
+shim is built - against the shim directly on fresh inputs.  Bit-exact everywhere (raw fp32 bit patterns)."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STEP_FILES = sorted(glob.glob(os.path.join(GOLD, "steps_*.npz")))
+
+
+def load_case(path):
+    z = np.load(path)
+    dt, growth, fw, fh = z["params"]
+    return z, int(z["n0"]), np.float32(dt), np.float32(growth), int(fw), int(fh)
+
+
+@pytest.mark.parametrize("path", STEP_FILES, ids=[os.path.basename(p)[6:-4] for p in STEP_FILES])
+def test_port_matches_golden_free_run(path):
+    z, n, dt, growth, fw, fh = load_case(path)
+    b = z["init"].view(np.float32).copy()
+    counts = z["counts"]
+    for s in range(1, len(counts) + 1):
+        n, st, ab, de, pre = ol.port_step(b, n, dt, fw, fh, growth, pre=("pre_%d" % s) in z)
+        assert n == counts[s - 1], (s, n, counts[s - 1])
+        assert st.n_after == n
+        if "pre_%d" % s in z:
+            assert np.array_equal(pre.view(np.uint32), z["pre_%d" % s])
+            # D_t is observable in the reference: deleted bodies are exactly those with mass 0 afterwards
+            n_before = len(pre) // 6
+            m_after = pre[4 * n_before:5 * n_before]
+            assert np.array_equal(np.nonzero(m_after == 0)[0], np.sort(de))
+        if "after_%d" % s in z:
+            assert np.array_equal(b[:6 * n].view(np.uint32), z["after_%d" % s]), "step %d" % s
+
+
+def test_port_matches_big_golden():
+    g = json.load(open(os.path.join(GOLD, "big_n65536.json")))
+    for name, kw in (("stock_radii", {}), ("radii0", {"minRadius": 0.0, "maxRadius": 0.0})):
+        import ppa_nbody_collisions_amd as nb
+        cfg = nb.stock_config(particleCount=65536, **kw)
+        bodies = nb.init_bodies(cfg)
+        b = bodies.contiguousData
+        n, st, ab, de, pre = ol.port_step(b, 65536, np.float32(0.2), 100000, 100000, np.float32(0.1),
+                                          want_events=False, pre=True)
+        e = g[name]
+        assert n == e["n1"]
+        assert hashlib.sha256(pre.tobytes()).hexdigest() == e["sha256_pre"]
+        assert hashlib.sha256(b[:6 * n].tobytes()).hexdigest() == e["sha256_post"]
+        assert st.pairs == ol.port().oracle_pairs_per_step(65536, ol.LITERAL)
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("n,steps,field", [(3, 4, 100000), (77, 10, 2000), (128, 10, 2000), (129, 3, 2000),
+                                           (131, 8, 2000), (254, 8, 3000), (256, 10, 3000), (383, 10, 3000),
+                                           (640, 12, 4000), (1500, 6, 100000)])
+def test_port_matches_literal_shim(n, steps, field):
+    a = ol.ref_init(n, field, field)
+    b = a.copy()
+    na = nb_ = n
+    for s in range(steps):
+        na, _ = ol.ref_step(a, na, np.float32(0.2), field, field, np.float32(0.1))
+        nb_, st, _, _, _ = ol.port_step(b, nb_, np.float32(0.2), field, field, np.float32(0.1))
+        assert na == nb_
+        assert np.array_equal(a[:6 * na].view(np.uint32), b[:6 * nb_].view(np.uint32)), (n, s)
+
+
+# bodies ignored per i under the truncated last tile (quirk Q1)
+@pytest.mark.parametrize("n,ignored", [(64, 0), (128, 0), (1024, 7), (16384, 127), (65536, 124), (262144, 112)])
+def test_jlist_quirk_mask(n, ignored):
+    L = ol.port()
+    out = np.zeros(n, dtype=np.int32)
+    for i in sorted({0, 1, min(127, n - 1), n // 2, n - 1}):
+        k = L.oracle_jlist(n, i, ol.LITERAL, out.ctypes.data)
+        js = out[:k]
+        assert k == n - 1 - ignored
+        assert len(np.unique(js)) == k and i not in js
+        if ignored:
+            nbk = n // 128
+            missing = np.setdiff1d(np.arange(n), np.append(js, i))
+            assert np.all(missing // 128 == (i // 128 - 1) % nbk)
+            assert np.all(missing % 128 >= n % 129)
+    assert L.oracle_pairs_per_step(n, ol.LITERAL) == (n - 1 - ignored) * n
+
+
+def test_jlist_ragged_and_edges():
+    L = ol.port()
+    out = np.zeros(4096, dtype=np.int32)
+    # N=1000: 7 blocks -> bodies 896..999 have no thread (quirk Q2)
+    assert L.oracle_jlist(1000, 896, ol.LITERAL, out.ctypes.data) == -1
+    k = L.oracle_jlist(1000, 895, ol.LITERAL, out.ctypes.data)
+    assert k == 128 * 6 + 1000 % 129 - 1 and len(np.unique(out[:k])) == k and 895 not in out[:k]
+    # N=129: one block, L=0 -> nothing interacts
+    assert L.oracle_jlist(129, 5, ol.LITERAL, out.ctypes.data) == 0
+    assert L.oracle_pairs_per_step(129, ol.LITERAL) == 0
+    # N=200: L=71; lanes t>=71 drop entry t%71 instead of themselves (SURVEY.md A.3 edge cases)
+    k = L.oracle_jlist(200, 100, ol.LITERAL, out.ctypes.data)
+    assert k == 70 and (100 % 71) not in out[:k]
+
+
+def test_range_equals_full_step():
+    b = ol.make_block(*_dense(700))
+    n = 700
+    P, V, M, R, dl, st = ol.port_range(b, n, 0, n, np.float32(0.2), 3000, 3000, np.float32(0.1))
+    parts = [ol.port_range(b, n, lo, hi, np.float32(0.2), 3000, 3000, np.float32(0.1))
+             for lo, hi in ((0, 233), (233, 466), (466, 700))]
+    for k, name in enumerate("PVMR"):
+        cat = np.concatenate([p[k] for p in parts])
+        assert np.array_equal(cat.view(np.uint32), (P, V, M, R)[k].view(np.uint32)), name
+    assert sum(p[5].pairs for p in parts) == st.pairs
+
+
+def _dense(n, seed=3):
+    rng = np.random.default_rng(seed)
+    P = rng.uniform(-2500, 2500, (n, 2)).astype(np.float32)
+    V = rng.uniform(-5, 5, (n, 2)).astype(np.float32)
+    M = rng.uniform(1e4, 1e16, n).astype(np.float32)
+    R = rng.uniform(20, 120, n).astype(np.float32)
+    return P, V, M, R
+
+
+def test_f64_step_consistency():
+    """fp64 has no reference (parity unpinned); check it agrees with fp32 to fp32 accuracy on a short run."""
+    P, V, M, R = _dense(300)
+    b32 = ol.make_block(P, V, M, R, np.float32)
+    b64 = ol.make_block(P, V, M, R, np.float64)
+    n32, *_ = ol.port_step(b32, 300, np.float32(0.2), 3000, 3000, np.float32(0.1))
+    n64, *_ = ol.port_step(b64, 300, float(np.float32(0.2)), 3000, 3000, float(np.float32(0.1)))
+    assert n32 == n64
+    p32, p64 = b32[:2 * n32], b64[:2 * n64]
+    assert np.max(np.abs(p32 - p64)) / np.max(np.abs(p64)) < 1e-6
