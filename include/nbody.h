@@ -218,9 +218,11 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updatedMasses, fl
 int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updatedMasses, const float* d_updatedRadii,
                                  int numBodies, float timestep, int numBlocks, void* stream);
 
-/* Device self-test used by the GPU test-suite: exhaustively compares the kernel's fp32 sqrt and reciprocal
- * against fp64-then-round on all 2^32 inputs; *mismatches receives {sqrt, rcp} mismatch counts. */
-int nbody_selftest_ieee_f32(int device, uint64_t mismatches[2]);
+/* Device self-test used by the GPU test-suite, exhaustive over all 2^32 fp32 inputs: the kernels' general
+ * sqrt and reciprocal against fp64-then-round, and the fast evaluation chain of the fp32 force kernel
+ * (rsq/rcp + fma corrections) against the general code on its whole guarded domain.
+ * mismatches = {sqrt, reciprocal, fast chain} mismatch counts; all must be 0. */
+int nbody_selftest_ieee_f32(int device, uint64_t mismatches[3]);
 
 #ifdef __cplusplus
 }

@@ -161,6 +161,42 @@ int read_meta(nbody_ctx* c) {
     return NBODY_OK;
 }
 
+// kernel_variant: 0 default | 1 v1 (one body per lane, compiler IEEE sqrt/div) | 2,3,4 v2 with M = 1,2,4
+template <typename T>
+void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
+
+#define NB_FORCES_ARGS(T)                                                                                 \
+    (const Rec<T>*)c->J, (const Vec2<T>*)c->Vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V, (const Meta*)c->meta, p, \
+        c->events, c->ev_cap, c->counters
+
+template <>
+void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblocks, bool log) {
+    if (log) hipLaunchKernelGGL((forces_v1<double, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
+    else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
+}
+
+template <int M>
+void launch_v2(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = (nblocks + M - 1) / M;
+    if (log) hipLaunchKernelGGL((forces_v2_f32<M, true>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_v2_f32<M, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+}
+
+template <>
+void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    switch (c->desc.kernel_variant) {
+        case 1:
+            if (log) hipLaunchKernelGGL((forces_v1<float, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+            else hipLaunchKernelGGL((forces_v1<float, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+            break;
+        case 3: launch_v2<2>(c, p, nblocks, log); break;
+        case 4: launch_v2<4>(c, p, nblocks, log); break;
+        case 0:
+        case 2:
+        default: launch_v2<1>(c, p, nblocks, log); break;   // 4 waves/SIMD at N=262144: best measured
+    }
+}
+
 template <typename T>
 int launch_compute(nbody_ctx* c) {
     const StepParams<T> p = make_params<T>(c->desc);
@@ -176,15 +212,7 @@ int launch_compute(nbody_ctx* c) {
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
     const bool log = (c->desc.flags & NBODY_FLAG_RECORD_EVENTS) != 0;
-    if (log) {
-        hipLaunchKernelGGL((forces_v1<T, true>), dim3(nblocks), dim3(kTile), 0, c->stream,
-                           (const Rec<T>*)c->J, (const Vec2<T>*)c->Vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V,
-                           (const Meta*)c->meta, p, c->events, c->ev_cap, c->counters);
-    } else {
-        hipLaunchKernelGGL((forces_v1<T, false>), dim3(nblocks), dim3(kTile), 0, c->stream,
-                           (const Rec<T>*)c->J, (const Vec2<T>*)c->Vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V,
-                           (const Meta*)c->meta, p, c->events, c->ev_cap, c->counters);
-    }
+    launch_forces<T>(c, p, nblocks, log);
     HIP_TRY(hipGetLastError());
     if (c->timing) {
         HIP_TRY(hipEventRecord(e1, c->stream));
@@ -638,22 +666,23 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const fl
     return NBODY_OK;
 }
 
-int nbody_selftest_ieee_f32(int device, uint64_t mismatches[2]) {
+int nbody_selftest_ieee_f32(int device, uint64_t mismatches[3]) {
     if (!mismatches) return nbody_fail(NBODY_ERR_INVALID, "nbody_selftest_ieee_f32: NULL");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return nbody_fail(NBODY_ERR_NO_DEVICE, "no HIP device visible");
     HIP_TRY(hipSetDevice(device));
     unsigned long long* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(d, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void**)&d, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, 3 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(selftest_ieee_f32, dim3(256 * 16), dim3(256), 0, 0, d);
     HIP_TRY(hipGetLastError());
-    unsigned long long h[2];
+    unsigned long long h[3];
     HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
     hipFree(d);
     mismatches[0] = h[0];
     mismatches[1] = h[1];
+    mismatches[2] = h[2];
     return NBODY_OK;
 }
 

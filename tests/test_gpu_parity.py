@@ -37,9 +37,9 @@ def assert_bodies_equal(got, want_block, n, what=""):
 def test_ieee_sqrt_and_reciprocal_exhaustive(nb):
     """All 2^32 fp32 inputs: the kernels' sqrt and 1/x are correctly rounded (what the oracle's x86 sqrtss /
     divss compute)."""
-    m = (ctypes.c_uint64 * 2)()
+    m = (ctypes.c_uint64 * 3)()
     assert nb.lib.nbody_selftest_ieee_f32(0, ctypes.byref(m)) == 0, nb.lib.nbody_last_error_string()
-    assert (m[0], m[1]) == (0, 0)
+    assert (m[0], m[1], m[2]) == (0, 0, 0)
 
 
 def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
@@ -47,13 +47,17 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
+VARIANTS = [0, 1, 3, 4]      # kernel_variant: default (v2, M=1) | v1 | v2 M=2 | v2 M=4
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("path", STEP_FILES, ids=[os.path.basename(p)[6:-4] for p in STEP_FILES])
-def test_golden_free_run(nb, path):
+def test_golden_free_run(nb, path, variant):
     z = np.load(path)
     dt, growth, fw, fh = z["params"]
     n0 = int(z["n0"])
     counts = z["counts"]
-    st = _stepper(nb, n0, int(fw), int(fh), np.float32(dt), np.float32(growth))
+    st = _stepper(nb, n0, int(fw), int(fh), np.float32(dt), np.float32(growth), kernel_variant=variant)
     st.upload(nb.BodiesData.from_block(z["init"].view(np.float32), n0))
     for s in range(1, len(counts) + 1):
         st.step(1)
@@ -96,6 +100,48 @@ def test_events_match_oracle(nb, n, field, steps):
         assert sorted(set(int(e["i"]) for e in ev[ev["kind"] == 1])) == sorted(int(d) for d in de), "D_t %d" % s
         cur = cur2
         assert_bodies_equal(st.download(), blk, cur, "step %d" % s)
+    st.close()
+
+
+def _nan_aware_equal(got, want):
+    g, w = np.asarray(got), np.asarray(want)
+    both_nan = np.isnan(g) & np.isnan(w)
+    return np.array_equal(bits(g)[~both_nan.ravel()], bits(w)[~both_nan.ravel()])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_extreme_values_take_the_general_path(nb, variant):
+    """Non-finite / huge / coincident / denormally close bodies: the fast evaluation chain must hand these to
+    the general code (per-tile coordinate bound, per-wave own-coordinate bound, per-pair distance flag).
+    NaN payloads differ between x86 and gfx950, so NaNs compare equal to NaNs."""
+    n = 2048
+    cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg)
+    P, V, M, R = bodies.Positions, bodies.Velocities, bodies.Masses, bodies.Radii
+    P[100] = [1e20, -3e25]            # beyond the 2^38 coordinate bound
+    P[300] = [np.inf, 5.0]
+    P[301] = [np.nan, 7.0]
+    P[500] = P[499]                   # coincident, radii 0: d2 == 0 <= 0 -> collision
+    P[700] = P[699] + np.float32([1e-30, 0])        # rounds to coincident
+    P[900] = [3e-25, 1e-26]
+    P[901] = [3e-25 + 1e-31, 1e-26]   # denormally small separation
+    P[1100] = [1.0e-3, 0]
+    P[1101] = [1.0e-3 + 2.0e-11, 0]
+    M[1300] = np.nan
+    M[1301] = np.inf
+    R[1500] = np.inf
+    R[1501] = np.nan
+    V[1700] = [1e30, -1e30]
+    st = nb.Stepper(cfg, kernel_variant=variant)
+    st.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    for s in range(4):
+        st.step(1)
+        cur, *_ = ol.port_step(blk, cur, DT, 100000, 100000, GROWTH, want_events=False)
+        out = st.download()
+        assert out.numBodies == cur, "step %d" % s
+        assert _nan_aware_equal(out.block, blk[:6 * cur]), "step %d" % s
     st.close()
 
 

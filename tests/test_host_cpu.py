@@ -135,7 +135,7 @@ def test_compute_fails_loudly_without_gpu(nb):
     with pytest.raises(nb.NbodyError) as ei:
         nb.Stepper(nb.stock_config(particleCount=128))
     assert ei.value.status == -5
-    m = (ctypes.c_uint64 * 2)()
+    m = (ctypes.c_uint64 * 3)()
     assert nb.lib.nbody_selftest_ieee_f32(0, ctypes.byref(m)) == -5
 
 
