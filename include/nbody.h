@@ -128,8 +128,11 @@ typedef enum nbody_semantics {
 
 enum { /* nbody_ctx_desc.flags */
     NBODY_FLAG_RECORD_EVENTS = 1u << 0,   /* keep the collision event log (E_t, D_t of SURVEY.md A.2)   */
-    NBODY_FLAG_GROUP_EXCHANGE = 1u << 1   /* world>1, every rank is a context of this process: the       */
+    NBODY_FLAG_GROUP_EXCHANGE = 1u << 1,  /* world>1, every rank is a context of this process: the       */
                                           /* exchange is done by nbody_group_step with peer copies        */
+    NBODY_FLAG_FORCE_COMM = 1u << 2       /* create the RCCL communicator and run the slot all-gather    */
+                                          /* even when world == 1 (exercises the multi-rank path on one  */
+                                          /* GPU)                                                         */
 };
 
 typedef struct nbody_ctx nbody_ctx;

@@ -21,6 +21,7 @@ F32, F64 = 0, 1
 LITERAL, CLEAN = 0, 1
 FLAG_RECORD_EVENTS = 1
 FLAG_GROUP_EXCHANGE = 2
+FLAG_FORCE_COMM = 4
 COMM_ID_BYTES = 128
 IMAGE_PATH_MAX = 1024
 
@@ -264,7 +265,7 @@ class Stepper:
 
     def __init__(self, cfg=None, capacity=None, precision=F32, semantics=LITERAL, device=0, rank=0, world=1,
                  record_events=False, group=False, comm_id=None, timestep=None, growthRate=None,
-                 fieldWidth=None, fieldHeight=None, event_capacity=0, kernel_variant=0):
+                 fieldWidth=None, fieldHeight=None, event_capacity=0, kernel_variant=0, force_comm=False):
         d = _CtxDesc()
         if cfg is not None:
             lib.nbody_ctx_desc_from_config(ctypes.byref(d), ctypes.byref(cfg), precision)
@@ -275,7 +276,8 @@ class Stepper:
                           ("fieldHeight", fieldHeight)):
             if val is not None:
                 setattr(d, name, val)
-        d.flags = (FLAG_RECORD_EVENTS if record_events else 0) | (FLAG_GROUP_EXCHANGE if group else 0)
+        d.flags = ((FLAG_RECORD_EVENTS if record_events else 0) | (FLAG_GROUP_EXCHANGE if group else 0) |
+                   (FLAG_FORCE_COMM if force_comm else 0))
         d.event_capacity = event_capacity
         d.kernel_variant = kernel_variant
         self._comm_id = ctypes.create_string_buffer(comm_id, COMM_ID_BYTES) if comm_id else None

@@ -53,9 +53,14 @@ int rccl_load() {
     if (g_rccl.lib) return NBODY_OK;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* lib = nullptr;
+    // a copy that is already in the process (PyTorch's) wins: never two RCCLs in one process
     for (const char* n : names) {
-        lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
         if (lib) break;
+    }
+    for (const char* n : names) {
+        if (lib) break;
+        lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
     }
     if (!lib) return nbody_fail(NBODY_ERR_COMM, "cannot dlopen librccl.so.1: %s", dlerror());
     Rccl r;
@@ -245,7 +250,7 @@ int launch_commit(nbody_ctx* c) {
 }
 
 int do_exchange(nbody_ctx* c) {
-    if (c->desc.world == 1) return NBODY_OK;     // gather aliases slot
+    if (c->gather == c->slot) return NBODY_OK;   // single rank: the gather buffer aliases the slot
     if (!c->comm) return nbody_fail(NBODY_ERR_STATE, "context has no communicator");
     RCCL_TRY(g_rccl.AllGather(c->slot, c->gather, c->slot_bytes, kNcclInt8, c->comm, c->stream));
     return NBODY_OK;
@@ -344,7 +349,8 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     CTX_TRY(hipMalloc(&c->S_J, (size_t)c->cap_own * c->rec_bytes));
     CTX_TRY(hipMalloc(&c->S_V, (size_t)c->cap_own * 2 * c->real_bytes));
     CTX_TRY(hipMalloc((void**)&c->slot, c->slot_bytes));
-    if (d->world > 1) CTX_TRY(hipMalloc((void**)&c->gather, c->slot_bytes * d->world));
+    const bool use_comm = (d->world > 1 && !(d->flags & NBODY_FLAG_GROUP_EXCHANGE)) || (d->flags & NBODY_FLAG_FORCE_COMM);
+    if (d->world > 1 || use_comm) CTX_TRY(hipMalloc((void**)&c->gather, c->slot_bytes * d->world));
     else c->gather = c->slot;
     CTX_TRY(hipMalloc((void**)&c->blk_counts, sizeof(int) * (size_t)(c->cap_own / kCompactBlock + 2)));
     CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
@@ -358,10 +364,10 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     CTX_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
 #undef CTX_TRY
 
-    if (d->world > 1 && !(d->flags & NBODY_FLAG_GROUP_EXCHANGE)) {
+    if (use_comm) {
         int rc = rccl_load();
         if (rc == NBODY_OK && !d->comm_id)
-            rc = nbody_fail(NBODY_ERR_INVALID, "world > 1 needs comm_id (nbody_comm_unique_id on rank 0)");
+            rc = nbody_fail(NBODY_ERR_INVALID, "an RCCL context needs comm_id (nbody_comm_unique_id on rank 0)");
         if (rc == NBODY_OK) {
             Id128 id;
             memcpy(id.b, d->comm_id, sizeof(id.b));
@@ -558,7 +564,7 @@ int nbody_download(nbody_ctx* c, void* block, int* n_out) {
         memcpy(R + rb * i, st + c->rec_bytes * i + 3 * rb, rb);
     }
     // velocities: own range from this rank; other ranks' through the slot machinery (padded all-gather)
-    if (c->desc.world == 1) {
+    if (c->desc.world == 1 && !c->comm) {
         HIP_TRY(hipMemcpyAsync(V, c->Vown, (size_t)cnt * 2 * rb, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     } else if (c->comm) {

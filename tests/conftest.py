@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# One ROCm runtime per process: some tests use torch (device memory for the reference-shaped launches, gloo).
+# torch bundles its own libamdhip64 / librccl; if the product library were loaded first it would bring in
+# /opt/rocm's copies and `import torch` would then load a SECOND HIP runtime.  Importing torch first makes the
+# product library (NEEDED libamdhip64.so.7, dlopen librccl.so.1) bind to the copies torch already loaded.
+try:
+    import torch  # noqa: F401
+except ImportError:  # the product itself does not need torch
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

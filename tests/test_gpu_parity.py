@@ -180,6 +180,20 @@ def test_sharded_group_equals_single(nb, world):
     grp.close()
 
 
+def test_rccl_path_single_rank(nb):
+    """The multi-rank code path on one GPU: RCCL loaded by dlopen, a 1-rank communicator from a unique id, the
+    per-step slot all-gather and the all-gather based download.  (N>1 ranks cannot run on a 1-GPU box; the
+    partition logic itself is covered by test_sharded_group_equals_single and the gloo CPU tests.)"""
+    z = np.load(os.path.join(GOLD, "steps_dense_n1000.npz"))
+    dt, growth, fw, fh = z["params"]
+    st = nb.Stepper(capacity=1000, timestep=float(dt), growthRate=float(growth), fieldWidth=int(fw),
+                    fieldHeight=int(fh), comm_id=nb.comm_unique_id(), force_comm=True)
+    st.upload(nb.BodiesData.from_block(z["init"].view(np.float32), 1000))
+    st.step(5)
+    assert_bodies_equal(st.download(), z["after_5"].view(np.float32), int(z["counts"][4]), "rccl world=1")
+    st.close()
+
+
 def test_full_size_sampled_parity_n262144(nb):
     """BASELINE.json metric size: one step at N=262144 on the GPU, oracle on a spread sample of bodies."""
     n = 262144
