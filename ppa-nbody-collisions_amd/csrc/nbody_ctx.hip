@@ -166,7 +166,8 @@ int read_meta(nbody_ctx* c) {
     return NBODY_OK;
 }
 
-// kernel_variant: 0 default | 1 v1 (one body per lane, compiler IEEE sqrt/div) | 2,3,4 v2 with M = 1,2,4
+// kernel_variant: 0 default | 1 v1 (one body per lane, compiler IEEE sqrt/div) | 2,3,4 v2 with M = 1,2,4 |
+//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -187,19 +188,34 @@ void launch_v2(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_v2_f32<M, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
+template <int K>
+void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = nblocks * K;
+    if (log) hipLaunchKernelGGL((forces_v3_f32<K, true>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+}
+
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     switch (c->desc.kernel_variant) {
         case 1:
             if (log) hipLaunchKernelGGL((forces_v1<float, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
             else hipLaunchKernelGGL((forces_v1<float, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
-            break;
-        case 3: launch_v2<2>(c, p, nblocks, log); break;
-        case 4: launch_v2<4>(c, p, nblocks, log); break;
-        case 0:
-        case 2:
-        default: launch_v2<1>(c, p, nblocks, log); break;   // 4 waves/SIMD at N=262144: best measured
+            return;
+        case 2: launch_v2<1>(c, p, nblocks, log); return;
+        case 3: launch_v2<2>(c, p, nblocks, log); return;
+        case 4: launch_v2<4>(c, p, nblocks, log); return;
+        case 11: launch_v3<1>(c, p, nblocks, log); return;
+        case 12: launch_v3<2>(c, p, nblocks, log); return;
+        case 14: launch_v3<4>(c, p, nblocks, log); return;
+        case 18: launch_v3<8>(c, p, nblocks, log); return;
+        default: break;
     }
+    // default: v3, lanes per body chosen so that the own range fills the chip (measured on MI355X with
+    // csrc/tune/scaling_probe.py at N=262144: K=1 down to ~128k bodies per rank, K=2 at 64k, K=4 at 32k)
+    if (c->own_upper >= 98304) launch_v3<1>(c, p, nblocks, log);
+    else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
+    else launch_v3<4>(c, p, nblocks, log);
 }
 
 template <typename T>
@@ -445,11 +461,16 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
         HIP_TRY(hipEventCreateWithFlags(&ready[g], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&done[g], hipEventDisableTiming));
     }
+    // NBODY_GROUP_SERIALIZE=1 (tuning aid): ranks that share one device run their compute phases one after the
+    // other, so each rank's kernel time is what a dedicated GPU would see
+    const bool serialize = getenv("NBODY_GROUP_SERIALIZE") != nullptr;
     int rc = NBODY_OK;
     for (int s = 0; s < nsteps && rc == NBODY_OK; ++s) {
         for (int g = 0; g < world && rc == NBODY_OK; ++g) {
             nbody_ctx* c = ctxs[g];
             HIP_TRY(hipSetDevice(c->desc.device));
+            if (serialize && g > 0) HIP_TRY(hipStreamWaitEvent(c->stream, ready[g - 1], 0));
+            if (serialize && g == 0 && s > 0) HIP_TRY(hipStreamWaitEvent(c->stream, done[world - 1], 0));
             // the slot of rank g may be rewritten only after every rank has copied it out (previous step)
             if (s > 0) for (int h = 0; h < world; ++h) if (h != g) HIP_TRY(hipStreamWaitEvent(c->stream, done[h], 0));
             rc = compute_phase(c);

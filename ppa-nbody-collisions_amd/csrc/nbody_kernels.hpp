@@ -439,6 +439,179 @@ __global__ __launch_bounds__(kTile) void forces_v2_f32(const Rec<float>* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Force + collision + drift kernel, variant "v3" (fp32): the production kernel.
+//
+//   * 128-lane workgroup = 128/K bodies of one reference block, K consecutive lanes per body.  Lane h of a
+//     group evaluates the tile entries off = h, h+K, h+2K, ... of the body's walk; the running force sum
+//     lives in lane h = 0 and takes the K terms of a round strictly in walk order (own term, then the
+//     neighbours' through DPP row_shl), so the fp32 accumulation order - and therefore every bit of the
+//     result - is independent of K.  K > 1 buys parallelism when a rank owns fewer bodies than the chip has
+//     lanes (strong scaling); K = 1 is one body per lane.
+//   * The tile is stored TWICE back to back in LDS, so entry (t+off) mod 128 is at index t+off without a wrap:
+//     the address of every pair's ds_read_b128 is one per-lane base plus an immediate offset.
+//   * Fast path (fast_chain) in chunks of 32 walk positions with a wave-wide flag per chunk; a flagged chunk
+//     is restored from a 2-register snapshot and redone by the general code in the chain lanes.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kChunk = 32;
+
+template <int U>
+__device__ __forceinline__ float dpp_row_shl(float v) {
+    // bound_ctrl:1 (out-of-row lanes read 0) lets the DPP combiner fold the move into the consuming v_add_f32
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + U, 0xf, 0xf, true));
+}
+
+template <int K, bool kLog>
+__global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __restrict__ J,
+                                                       const Vec2<float>* __restrict__ Vown,
+                                                       Rec<float>* __restrict__ S_J,
+                                                       Vec2<float>* __restrict__ S_V,
+                                                       const Meta* __restrict__ meta, StepParams<float> p,
+                                                       Event* ev, int ev_cap, Counters* ctr) {
+    typedef float T;
+    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "K lanes per body");
+    constexpr int kBodies = kTile / K;                     // bodies per workgroup
+    __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
+    __shared__ int tile_bad[2][kTile / kWave];
+    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    const int lane = threadIdx.x;
+    const int wave = lane / kWave;
+    const int h = lane % K;                                // slice of the walk this lane evaluates
+    const int bl = lane / K;                               // body within the workgroup
+    const int wg = blockIdx.x;
+    const int b = lo / kTile + wg / K;                     // reference block
+    const int t = (wg % K) * kBodies + bl;                 // threadIdx.x of this body in the reference
+    const long long blk0 = (long long)b * kTile;
+    if (blk0 + (wg % K) * kBodies >= (long long)lo + cnt) return;
+    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
+    const bool loader = lane < N || N >= kTile;            // N < 128: lanes >= N load nothing (:143)
+
+    const long long i64 = blk0 + t;
+    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
+    const bool active = mine && i64 < N && i64 < (long long)nb * kTile;
+    const bool chain = h == 0;                             // lane that owns the accumulators
+    BodyAcc<T> a;
+    Vec2<T> v{0, 0};
+    if (mine) {
+        const Rec<T> me = J[i];
+        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
+        v = Vown[i - lo];
+    } else {
+        a.xi = a.yi = a.mi = a.ri = 0;
+    }
+    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
+    const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
+    const bool wave_ok = __ballot(!lane_ok) == 0ull;
+    unsigned long long pairs = 0;
+
+    long long start = blk0 % N;                            // first body of the current tile (cyclic)
+    auto entry_index = [&](long long st) -> int {
+        long long src = st + lane;
+        if (src >= N) src -= N;
+        if (src >= N) src %= N;                            // only when N < 128
+        return (int)src;
+    };
+    auto coord_bad = [](const Rec<T>& r) -> bool {
+        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
+    };
+    {
+        Rec<T> r{0, 0, 0, 0};
+        if (loader) { r = J[entry_index(start)]; tile[0][lane] = r; tile[0][lane + kTile] = r; }
+        const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
+        if ((lane & (kWave - 1)) == 0) tile_bad[0][wave] = bad;
+    }
+    __syncthreads();
+
+    for (int k = 0; k < nb; ++k) {                         // :182, tile k of this body = cyclic tile b + k
+        const int cur = k & 1;
+        const bool have_next = k + 1 < nb;
+        long long next_start = start + kTile;
+        while (next_start >= N) next_start -= N;
+        Rec<T> nxt{0, 0, 0, 0};
+        if (have_next && loader) nxt = J[entry_index(next_start)];
+
+        const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;                // :194 (quirk Q1)
+        // general code on walk positions [o0, o1) of this tile, by the chain lane, exact for every input
+        auto general = [&](int o0, int o1) {
+            if (!(active && chain)) return;
+            for (int off = o0; off < o1; ++off) {
+                if (k == 0 && off == 0) continue;                              // :200-204
+                const int s = (L == kTile) ? (t + off) : ((t + off) % L);      // :207 (doubled tile: no wrap)
+                long long j = start + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
+                if (j >= N) j %= N;
+                interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+            }
+        };
+        bool bad_tile = false;
+#pragma unroll
+        for (int w = 0; w < kTile / kWave; ++w) bad_tile = bad_tile || tile_bad[cur][w] != 0;
+        const bool interior = k >= 1 && k <= nb - 2;
+        if (interior && wave_ok && !bad_tile) {
+            const Rec<T>* walk = &tile[cur][t + h];        // entry of walk position off = h
+#pragma unroll 1
+            for (int c = 0; c < kTile / kChunk; ++c) {
+                const float fx0 = a.fx, fy0 = a.fy;
+                float fx = fx0, fy = fy0;
+                unsigned long long flag = 0;
+#pragma unroll 8
+                for (int r = 0; r < kChunk / K; ++r) {
+                    const Rec<T> bj = walk[c * kChunk + r * K];
+                    const float dx = bj.x - a.xi;
+                    const float dy = bj.y - a.yi;
+                    const float d2 = (dx * dx) + (dy * dy);
+                    const float rs = a.ri + bj.r;
+                    const float q = __builtin_fmaf(rs, rs, kFastLo);           // flag only
+                    flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
+                    const FastChain ch = fast_chain(d2);
+                    const float tx = ch.inv * (bj.m * dx);
+                    const float ty = ch.inv * (bj.m * dy);
+                    fx = fx + tx;                           // walk position r*K + 0
+                    fy = fy + ty;
+                    if (K > 1) { fx = fx + dpp_row_shl<1>(tx); fy = fy + dpp_row_shl<1>(ty); }
+                    if (K > 2) { fx = fx + dpp_row_shl<2>(tx); fy = fy + dpp_row_shl<2>(ty);
+                                 fx = fx + dpp_row_shl<3>(tx); fy = fy + dpp_row_shl<3>(ty); }
+                    if (K > 4) { fx = fx + dpp_row_shl<4>(tx); fy = fy + dpp_row_shl<4>(ty);
+                                 fx = fx + dpp_row_shl<5>(tx); fy = fy + dpp_row_shl<5>(ty);
+                                 fx = fx + dpp_row_shl<6>(tx); fy = fy + dpp_row_shl<6>(ty);
+                                 fx = fx + dpp_row_shl<7>(tx); fy = fy + dpp_row_shl<7>(ty); }
+                }
+                if (flag == 0ull) {
+                    a.fx = fx; a.fy = fy;
+                } else {       // a collision / tiny distance somewhere in this wave's chunk: redo it exactly
+                    a.fx = fx0; a.fy = fy0;
+                    general(c * kChunk, c * kChunk + kChunk);
+                }
+            }
+        } else {
+            general(0, L);
+        }
+        if (active && chain) pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+        if (have_next) {
+            if (loader) { tile[cur ^ 1][lane] = nxt; tile[cur ^ 1][lane + kTile] = nxt; }
+            const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
+            if ((lane & (kWave - 1)) == 0) tile_bad[cur ^ 1][wave] = bad;
+        }
+        __syncthreads();
+        start = next_start;
+    }
+
+    if (mine && chain) {
+        const int q = i - lo;
+        if (active) {
+            Rec<T> out; Vec2<T> vout;
+            finish_body<T>(a, v, p, out, vout);
+            S_J[q] = out;
+            S_V[q] = vout;
+        } else {       // frozen body: no thread exists for it in the reference, state carried over unchanged
+            S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
+            S_V[q] = v;
+        }
+    }
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
+    if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Stable compaction of the own range on `mass != 0` (src/nbody.cu:488-510), two small kernels.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCompactBlock = 1024;

@@ -47,7 +47,7 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-VARIANTS = [0, 1, 3, 4]      # kernel_variant: default (v2, M=1) | v1 | v2 M=2 | v2 M=4
+VARIANTS = [0, 1, 3, 4, 11, 12, 14, 18]   # default | v1 | v2 M=2,4 | v3 K=1,2,4,8 (csrc/nbody_ctx.hip)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
