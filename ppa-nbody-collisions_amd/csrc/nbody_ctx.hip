@@ -167,7 +167,7 @@ int read_meta(nbody_ctx* c) {
 }
 
 // kernel_variant: 0 default | 1 v1 (one body per lane, compiler IEEE sqrt/div) | 2,3,4 v2 with M = 1,2,4 |
-//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body
+//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 22,24,28 producer/consumer with P = 2,4,8
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -195,6 +195,14 @@ void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
+template <int C, int P, int S>
+void launch_pc(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = nblocks * (kTile / (kWave * C));
+    const int threads = kWave * C * (1 + P);
+    if (log) hipLaunchKernelGGL((forces_pc_f32<C, P, S, true>), dim3(grid), dim3(threads), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_pc_f32<C, P, S, false>), dim3(grid), dim3(threads), 0, c->stream, NB_FORCES_ARGS(float));
+}
+
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     switch (c->desc.kernel_variant) {
@@ -209,13 +217,20 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 12: launch_v3<2>(c, p, nblocks, log); return;
         case 14: launch_v3<4>(c, p, nblocks, log); return;
         case 18: launch_v3<8>(c, p, nblocks, log); return;
+        case 22: launch_pc<1, 2, 16>(c, p, nblocks, log); return;
+        case 24: launch_pc<1, 4, 32>(c, p, nblocks, log); return;
+        case 25: launch_pc<2, 4, 32>(c, p, nblocks, log); return;
+        case 28: launch_pc<1, 8, 64>(c, p, nblocks, log); return;
         default: break;
     }
-    // default: v3, lanes per body chosen so that the own range fills the chip (measured on MI355X with
-    // csrc/tune/scaling_probe.py at N=262144: K=1 down to ~128k bodies per rank, K=2 at 64k, K=4 at 32k)
+    // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
+    // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144, profiles/r01_scaling_probe_*.txt):
+    //   >= 96k bodies : one lane per body                          (4 / 2 waves per SIMD)
+    //   >= 48k        : two lanes per body, DPP chain
+    //   below         : producer/consumer, 4 producer waves per chain wave
     if (c->own_upper >= 98304) launch_v3<1>(c, p, nblocks, log);
     else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
-    else launch_v3<4>(c, p, nblocks, log);
+    else launch_pc<1, 4, 32>(c, p, nblocks, log);
 }
 
 template <typename T>
