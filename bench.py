@@ -29,6 +29,15 @@ PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def measured_traffic(a, world):
+    """HBM-side bytes per force-kernel launch from the committed rocprofv3 PMC passes (profiles/, collected
+    and corrected as MI355X_MICROARCH.md prescribes). Only valid for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    if world != 1 or a.bodies != 262144 or a.fp64 or a.stock_radii or a.variant != 0 or not os.path.exists(path):
+        return None
+    return json.load(open(path))["forces_kernel_traffic_bytes_per_launch"]
+
+
 def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
     """Times the CPU oracle (oracle/nbody_oracle.c, OpenMP over i) on a bounded sample of the same workload:
     a contiguous range of i-bodies of step 1, every one against all its j's.  Checker used as the reported
@@ -157,7 +166,7 @@ def main():
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": None, "kernel": "forces", "kernel_ms": k_ms,
+                         "traffic": measured_traffic(a, world), "kernel": "forces", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_valu": {"bound": "valu_fp32" if not a.fp64 else "valu_fp64",
                               "achieved": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12, "peak": peak_valu,
