@@ -112,6 +112,7 @@ struct nbody_ctx {
     void* h_stage = nullptr;    // pinned, max(cap*rec, cap*2*real ...)
     size_t h_stage_bytes = 0;
     Meta* h_meta = nullptr;     // pinned
+    Meta* h_meta_async = nullptr;   // pinned; refreshed by an un-waited D2H copy after every step
     Counters* h_counters = nullptr;
     int n_upper = 0;            // host-side upper bound of the global count (exact after a sync)
     int own_upper = 0;          // upper bound of the own count
@@ -236,6 +237,11 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
 template <typename T>
 int launch_compute(nbody_ctx* c) {
     const StepParams<T> p = make_params<T>(c->desc);
+    {
+        const int cnt_seen = *(volatile int*)&c->h_meta_async->cnt, n_seen = *(volatile int*)&c->h_meta_async->n;
+        if (cnt_seen > 0 && cnt_seen < c->own_upper) c->own_upper = cnt_seen;
+        if (n_seen > 0 && n_seen < c->n_upper) c->n_upper = n_seen;
+    }
     // Workgroups cover every reference block that can intersect the own range: a range of cnt bodies
     // touches at most cnt/128 + 2 blocks wherever it starts.  The count only shrinks between syncs, so the
     // host-side upper bound is safe; the kernel takes the exact range from the device-side Meta and
@@ -292,8 +298,12 @@ int compute_phase(nbody_ctx* c) {
 }
 int commit_phase(nbody_ctx* c) {
     int rc = c->desc.precision == NBODY_F64 ? launch_commit<double>(c) : launch_commit<float>(c);
-    if (rc == NBODY_OK) c->steps += 1;
-    return rc;
+    if (rc != NBODY_OK) return rc;
+    c->steps += 1;
+    // Counts only shrink, so a count read back late is still an upper bound: copy Meta to pinned memory
+    // without waiting and let later launches size their grids / pick their kernel from whatever has landed.
+    HIP_TRY(hipMemcpyAsync(c->h_meta_async, c->meta, sizeof(Meta), hipMemcpyDeviceToHost, c->stream));
+    return NBODY_OK;
 }
 
 void free_all(nbody_ctx* c) {
@@ -308,6 +318,7 @@ void free_all(nbody_ctx* c) {
     hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->counters); hipFree(c->events);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_meta) hipHostFree(c->h_meta);
+    if (c->h_meta_async) hipHostFree(c->h_meta_async);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -392,6 +403,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     c->h_stage_bytes = (size_t)c->cap * c->rec_bytes;
     CTX_TRY(hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
     CTX_TRY(hipHostMalloc((void**)&c->h_meta, sizeof(Meta), hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc((void**)&c->h_meta_async, sizeof(Meta), hipHostMallocDefault));
     CTX_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
 #undef CTX_TRY
 
@@ -448,6 +460,7 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
         HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
     }
     c->h_meta->n = n; c->h_meta->lo = lo; c->h_meta->cnt = cnt; c->h_meta->step = 0;
+    *c->h_meta_async = *c->h_meta;
     HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

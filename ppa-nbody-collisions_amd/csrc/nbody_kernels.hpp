@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
     constexpr int kBodies = kTile / K;                     // bodies per workgroup
     __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
     __shared__ int tile_bad[2][kTile / kWave];
+    __shared__ int tile_rnz[2][kTile / kWave];            // some radius in the staged tile is not +0
     const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
     const int lane = threadIdx.x;
     const int wave = lane / kWave;
@@ -502,6 +504,8 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
     a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
     const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
     const bool wave_ok = __ballot(!lane_ok) == 0ull;
+    // all radii of this wave's bodies are +0.0f: with an all-zero tile the radius sum is exactly +0
+    const bool wave_r0 = __ballot(active && __float_as_uint(a.ri) != 0u) == 0ull;
     unsigned long long pairs = 0;
 
     long long start = blk0 % N;                            // first body of the current tile (cyclic)
@@ -518,7 +522,8 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
         Rec<T> r{0, 0, 0, 0};
         if (loader) { r = J[entry_index(start)]; tile[0][lane] = r; tile[0][lane + kTile] = r; }
         const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
-        if ((lane & (kWave - 1)) == 0) tile_bad[0][wave] = bad;
+        const bool rnz = __ballot(loader && __float_as_uint(r.r) != 0u) != 0ull;
+        if ((lane & (kWave - 1)) == 0) { tile_bad[0][wave] = bad; tile_rnz[0][wave] = rnz; }
     }
     __syncthreads();
 
@@ -548,40 +553,53 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
         const bool interior = k >= 1 && k <= nb - 2;
         if (interior && wave_ok && !bad_tile) {
             const Rec<T>* walk = &tile[cur][t + h];        // entry of walk position off = h
+            bool rnz_tile = false;
+#pragma unroll
+            for (int w = 0; w < kTile / kWave; ++w) rnz_tile = rnz_tile || tile_rnz[cur][w] != 0;
+            // kR0: every radius involved is +0.0f, so rs = +0 and q = fma(0, 0, 2^-80) = 2^-80 exactly: the
+            // radius sum and the fma are skipped, the flag test is unchanged
+            auto chunks = [&](auto r0_tag) {
+                constexpr bool kR0 = decltype(r0_tag)::value;
 #pragma unroll 1
-            for (int c = 0; c < kTile / kChunk; ++c) {
-                const float fx0 = a.fx, fy0 = a.fy;
-                float fx = fx0, fy = fy0;
-                unsigned long long flag = 0;
+                for (int c = 0; c < kTile / kChunk; ++c) {
+                    const float fx0 = a.fx, fy0 = a.fy;
+                    float fx = fx0, fy = fy0;
+                    unsigned long long flag = 0;
 #pragma unroll 8
-                for (int r = 0; r < kChunk / K; ++r) {
-                    const Rec<T> bj = walk[c * kChunk + r * K];
-                    const float dx = bj.x - a.xi;
-                    const float dy = bj.y - a.yi;
-                    const float d2 = (dx * dx) + (dy * dy);
-                    const float rs = a.ri + bj.r;
-                    const float q = __builtin_fmaf(rs, rs, kFastLo);           // flag only
-                    flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
-                    const FastChain ch = fast_chain(d2);
-                    const float tx = ch.inv * (bj.m * dx);
-                    const float ty = ch.inv * (bj.m * dy);
-                    fx = fx + tx;                           // walk position r*K + 0
-                    fy = fy + ty;
-                    if (K > 1) { fx = fx + dpp_row_shl<1>(tx); fy = fy + dpp_row_shl<1>(ty); }
-                    if (K > 2) { fx = fx + dpp_row_shl<2>(tx); fy = fy + dpp_row_shl<2>(ty);
-                                 fx = fx + dpp_row_shl<3>(tx); fy = fy + dpp_row_shl<3>(ty); }
-                    if (K > 4) { fx = fx + dpp_row_shl<4>(tx); fy = fy + dpp_row_shl<4>(ty);
-                                 fx = fx + dpp_row_shl<5>(tx); fy = fy + dpp_row_shl<5>(ty);
-                                 fx = fx + dpp_row_shl<6>(tx); fy = fy + dpp_row_shl<6>(ty);
-                                 fx = fx + dpp_row_shl<7>(tx); fy = fy + dpp_row_shl<7>(ty); }
+                    for (int r = 0; r < kChunk / K; ++r) {
+                        const Rec<T> bj = walk[c * kChunk + r * K];
+                        const float dx = bj.x - a.xi;
+                        const float dy = bj.y - a.yi;
+                        const float d2 = (dx * dx) + (dy * dy);
+                        float q = kFastLo;
+                        if (!kR0) {
+                            const float rs = a.ri + bj.r;
+                            q = __builtin_fmaf(rs, rs, kFastLo);               // flag only
+                        }
+                        flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
+                        const FastChain ch = fast_chain(d2);
+                        const float tx = ch.inv * (bj.m * dx);
+                        const float ty = ch.inv * (bj.m * dy);
+                        fx = fx + tx;                       // walk position r*K + 0
+                        fy = fy + ty;
+                        if (K > 1) { fx = fx + dpp_row_shl<1>(tx); fy = fy + dpp_row_shl<1>(ty); }
+                        if (K > 2) { fx = fx + dpp_row_shl<2>(tx); fy = fy + dpp_row_shl<2>(ty);
+                                     fx = fx + dpp_row_shl<3>(tx); fy = fy + dpp_row_shl<3>(ty); }
+                        if (K > 4) { fx = fx + dpp_row_shl<4>(tx); fy = fy + dpp_row_shl<4>(ty);
+                                     fx = fx + dpp_row_shl<5>(tx); fy = fy + dpp_row_shl<5>(ty);
+                                     fx = fx + dpp_row_shl<6>(tx); fy = fy + dpp_row_shl<6>(ty);
+                                     fx = fx + dpp_row_shl<7>(tx); fy = fy + dpp_row_shl<7>(ty); }
+                    }
+                    if (flag == 0ull) {
+                        a.fx = fx; a.fy = fy;
+                    } else {   // a collision / tiny distance somewhere in this wave's chunk: redo it exactly
+                        a.fx = fx0; a.fy = fy0;
+                        general(c * kChunk, c * kChunk + kChunk);
+                    }
                 }
-                if (flag == 0ull) {
-                    a.fx = fx; a.fy = fy;
-                } else {       // a collision / tiny distance somewhere in this wave's chunk: redo it exactly
-                    a.fx = fx0; a.fy = fy0;
-                    general(c * kChunk, c * kChunk + kChunk);
-                }
-            }
+            };
+            if (wave_r0 && !rnz_tile) chunks(std::true_type{});
+            else chunks(std::false_type{});
         } else {
             general(0, L);
         }
@@ -589,7 +607,8 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
         if (have_next) {
             if (loader) { tile[cur ^ 1][lane] = nxt; tile[cur ^ 1][lane + kTile] = nxt; }
             const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
-            if ((lane & (kWave - 1)) == 0) tile_bad[cur ^ 1][wave] = bad;
+            const bool rnz = __ballot(loader && __float_as_uint(nxt.r) != 0u) != 0ull;
+            if ((lane & (kWave - 1)) == 0) { tile_bad[cur ^ 1][wave] = bad; tile_rnz[cur ^ 1][wave] = rnz; }
         }
         __syncthreads();
         start = next_start;
