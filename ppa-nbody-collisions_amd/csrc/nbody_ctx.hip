@@ -204,6 +204,13 @@ void launch_pc(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_pc_f32<C, P, S, false>), dim3(grid), dim3(threads), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
+template <int W, int CS, int SLOTS>
+void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
+    if (log) hipLaunchKernelGGL((forces_ring_f32<W, CS, SLOTS, true>), dim3(grid), dim3(kWave * W), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_f32<W, CS, SLOTS, false>), dim3(grid), dim3(kWave * W), 0, c->stream, NB_FORCES_ARGS(float));
+}
+
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     switch (c->desc.kernel_variant) {
@@ -222,6 +229,9 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 24: launch_pc<1, 4, 32>(c, p, nblocks, log); return;
         case 25: launch_pc<2, 4, 32>(c, p, nblocks, log); return;
         case 28: launch_pc<1, 8, 64>(c, p, nblocks, log); return;
+        case 32: launch_ring<2, 15, 2>(c, p, nblocks, log); return;
+        case 34: launch_ring<4, 6, 4>(c, p, nblocks, log); return;
+        case 38: launch_ring<8, 1, 8>(c, p, nblocks, log); return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
@@ -684,6 +694,9 @@ int nbody_get_stats(nbody_ctx* c, nbody_stats* out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     rc = resolve_timing(c);
     if (rc != NBODY_OK) return rc;
+    if (c->h_counters->errors != 0)
+        return nbody_fail(NBODY_ERR_HIP, "device reported %llu in-kernel hand-off time-outs: results are invalid",
+                          (unsigned long long)c->h_counters->errors);
     out->steps = c->steps;
     out->pairs = (int64_t)c->h_counters->pairs;
     out->force_kernel_ms = c->force_ms;
