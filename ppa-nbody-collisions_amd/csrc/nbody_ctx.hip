@@ -204,13 +204,6 @@ void launch_pc(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_pc_f32<C, P, S, false>), dim3(grid), dim3(threads), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-template <int W, int CS, int SLOTS>
-void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
-    const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<W, CS, SLOTS, true>), dim3(grid), dim3(kWave * W), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_f32<W, CS, SLOTS, false>), dim3(grid), dim3(kWave * W), 0, c->stream, NB_FORCES_ARGS(float));
-}
-
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     switch (c->desc.kernel_variant) {
@@ -229,9 +222,6 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 24: launch_pc<1, 4, 32>(c, p, nblocks, log); return;
         case 25: launch_pc<2, 4, 32>(c, p, nblocks, log); return;
         case 28: launch_pc<1, 8, 64>(c, p, nblocks, log); return;
-        case 32: launch_ring<2, 15, 2>(c, p, nblocks, log); return;
-        case 34: launch_ring<4, 6, 4>(c, p, nblocks, log); return;
-        case 38: launch_ring<8, 1, 8>(c, p, nblocks, log); return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with

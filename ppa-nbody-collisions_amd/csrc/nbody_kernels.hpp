@@ -860,327 +860,6 @@ __global__ __launch_bounds__(kWave * C * (1 + P)) void forces_pc_f32(const Rec<f
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "ring" (fp32): barrier-free producer/consumer.
-//
-// Same idea as "pc" (a chain wave with one lane per body takes the terms in walk order, other waves evaluate
-// them), but nothing runs in lock step:
-//   * W waves per 64 bodies.  A walk is cut into blocks of kRB = 4 positions.  Wave 0 (the chain wave) owns kCS
-//     of every 32 blocks and evaluates them itself when it reaches them; the other blocks are dealt round-robin
-//     to the W-1 producer waves.  kCS is chosen so that all W waves carry the same instruction count.
-//   * A producer writes the 4 terms of a block (+ its 64-bit collision-flag mask) into slot g mod kSlots of an
-//     LDS ring and then bumps its progress counter; the chain wave waits only for the producer of the block it
-//     needs next; a producer waits only when the ring is full (chain progress counter).  All waits are polls
-//     of LDS words with workgroup-scope acquire/release, bounded, and abort the whole kernel on a time-out.
-//   * Tiles are staged by the chain wave (it is the last reader of the buffer being replaced) and published
-//     through a tile counter; per-tile "unbounded coordinates" bits live in a bitmap that is never rewritten.
-// The only barrier is the one after the prologue.  Results are bit-identical to every other variant.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kRB = 8;                       // walk positions per block
-constexpr int kBlocksPerTile = kTile / kRB;  // 16
-constexpr int kPattern = 32;                 // ownership pattern period in blocks (two tiles)
-constexpr int kGrp = 2;                      // blocks the chain wave takes per group (16 positions)
-constexpr unsigned kSpinLimit = 1u << 24;
-
-struct RingSync {
-    unsigned prog[8];        // blocks finished by producer wave w (index w-1)
-    unsigned consumed;       // blocks of the walk the chain wave is done with (global block count)
-    unsigned tile_ready;     // number of tiles staged so far
-    unsigned wg_bad;         // some own body has unbounded coordinates
-    unsigned abort;          // a wait timed out
-};
-
-__device__ __forceinline__ unsigned lds_load_acquire(unsigned* p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store_release(unsigned* p, unsigned v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// wave-uniform bounded wait for *p >= need; false = give up (abort set)
-__device__ __forceinline__ bool ring_wait(unsigned* p, unsigned need, unsigned* abort_word) {
-    unsigned spins = 0;
-    for (;;) {
-        if ((int)(lds_load_acquire(p) - need) >= 0) return true;
-        if (++spins > kSpinLimit || lds_load_acquire(abort_word) != 0u) {
-            lds_store_release(abort_word, 1u);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-template <int W, int kCS, int kSlots, bool kLog>
-__global__ __launch_bounds__(kWave * W, 4) void forces_ring_f32(const Rec<float>* __restrict__ J,
-                                                             const Vec2<float>* __restrict__ Vown,
-                                                             Rec<float>* __restrict__ S_J,
-                                                             Vec2<float>* __restrict__ S_V,
-                                                             const Meta* __restrict__ meta, StepParams<float> p,
-                                                             Event* ev, int ev_cap, Counters* ctr) {
-    typedef float T;
-    static_assert(W >= 2 && W <= 9 && kCS >= 1 && kCS < kPattern, "ring geometry");
-    static_assert(kSlots % kGrp == 0 && kBlocksPerTile % kGrp == 0, "groups must not straddle");
-    constexpr int kMaxTiles = 16384;                       // bitmap capacity (N up to 2 Mi bodies)
-    struct alignas(16) Term2 { float x0, y0, x1, y1; };
-    __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
-    __shared__ Term2 ring[kSlots][kRB / 2][kWave];
-    __shared__ unsigned long long ring_flag[kSlots];
-    __shared__ unsigned bad_bits[kMaxTiles / 32];
-    __shared__ RingSync sync;
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-    const int tid = threadIdx.x;
-    const int wave = tid / kWave;                          // 0 = chain wave
-    const int l = tid % kWave;
-    const int wg = blockIdx.x;
-    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
-    const int t = (wg % 2) * kWave + l;                    // threadIdx.x of this lane's body in the reference
-    const long long blk0 = (long long)b * kTile;
-    if (blk0 + (wg % 2) * kWave >= (long long)lo + cnt) return;
-    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool chainw = wave == 0;
-
-    const long long i64 = blk0 + t;
-    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && i64 < (long long)nb * kTile;
-    BodyAcc<T> a;
-    Vec2<T> v{0, 0};
-    if (mine) {
-        const Rec<T> me = J[i];
-        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
-        if (chainw) v = Vown[i - lo];
-    } else {
-        a.xi = a.yi = a.mi = a.ri = 0;
-    }
-    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
-    unsigned long long pairs = 0;
-
-    // ---- prologue: zero the sync words and the bitmap, then the only barrier of the kernel ----------------
-    for (int w = tid; w < kMaxTiles / 32; w += kWave * W) bad_bits[w] = 0;
-    if (tid < 8) sync.prog[tid] = 0;
-    if (tid == 0) { sync.consumed = 0; sync.tile_ready = 0; sync.wg_bad = 0; sync.abort = 0; }
-    __syncthreads();
-
-    // cyclic tile k of these bodies starts at body (blk0 + 128 k) mod N; entry e of a tile is body start + e
-    auto tile_start = [&](int k) -> long long { return (blk0 + (long long)kTile * k) % N; };
-    auto entry_index = [&](long long st, int e) -> int {
-        long long src = st + e;
-        if (src >= N) src -= N;
-        if (src >= N) src %= N;
-        return (int)src;
-    };
-    auto coord_bad = [](const Rec<T>& r) -> bool {
-        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
-    };
-    const bool small_n = N < kTile;                        // lanes >= N load nothing (:143)
-    // does the chain wave evaluate block g itself?  kCS of every kPattern consecutive blocks, evenly spread
-    auto chain_owns = [](unsigned g) -> bool {
-        const unsigned j = g % kPattern;
-        return ((j + 1) * kCS) / kPattern > (j * kCS) / kPattern;
-    };
-    // the fast evaluation of one walk position, shared by both roles
-    auto term = [&](const Rec<T>& bj, unsigned long long& flag, float& tx, float& ty) {
-        const float dx = bj.x - a.xi;
-        const float dy = bj.y - a.yi;
-        const float d2 = (dx * dx) + (dy * dy);
-        const float rs = a.ri + bj.r;
-        const float q = __builtin_fmaf(rs, rs, kFastLo);                       // flag only
-        flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
-        const FastChain ch = fast_chain(d2);
-        tx = ch.inv * (bj.m * dx);
-        ty = ch.inv * (bj.m * dy);
-    };
-
-    if (nb > kMaxTiles) {                                  // cannot happen for N <= 2 Mi; refuse loudly
-        if (tid == 0) atomicAdd(&ctr->errors, 1ull);
-        return;
-    }
-
-    if (chainw) {
-        // =================================== chain wave ====================================================
-        __builtin_amdgcn_s_setprio(3);
-        const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
-        const bool all_ok = __ballot(!lane_ok) == 0ull;
-        if (!all_ok && l == 0) sync.wg_bad = 1;
-        auto load_tile = [&](int kk, Rec<T>& r0, Rec<T>& r1) {
-            const long long st = tile_start(kk);
-            r0 = Rec<T>{0, 0, 0, 0}; r1 = r0;
-            if (!small_n || l < N) r0 = J[entry_index(st, l)];
-            if (!small_n || l + kWave < N) r1 = J[entry_index(st, l + kWave)];
-        };
-        auto store_tile = [&](int kk, const Rec<T>& r0, const Rec<T>& r1) {
-            Rec<T>* tb = tile[kk & 1];
-            tb[l] = r0; tb[l + kTile] = r0;
-            tb[l + kWave] = r1; tb[l + kWave + kTile] = r1;
-            const bool bad = __ballot(coord_bad(r0) || coord_bad(r1)) != 0ull;
-            if (bad && l == 0) atomicOr(&bad_bits[kk / 32], 1u << (kk % 32));
-            if (l == 0) lds_store_release(&sync.tile_ready, (unsigned)(kk + 1));
-        };
-        auto general = [&](int kk, long long st, int o0, int o1) {
-            const int L = (kk == nb - 1) ? N % (kTile + 1) : kTile;               // :194 (quirk Q1)
-            const int hi = o1 < L ? o1 : L;
-            for (int off = o0; off < hi; ++off) {
-                if (kk == 0 && off == 0) continue;                                 // :200-204
-                const int s = (L == kTile) ? (t + off) : ((t + off) % L);          // :207 (doubled tile: no wrap)
-                long long j = st + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
-                if (j >= N) j %= N;
-                interact<T, kLog>(a, tile[kk & 1][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-            }
-        };
-        Rec<T> n0, n1;
-        load_tile(0, n0, n1);
-        store_tile(0, n0, n1);
-        if (nb > 1) load_tile(1, n0, n1);
-        unsigned gbase = 0;                                // global index of block 0 of the current fast tile
-        unsigned nonchain = 0;                             // producers' blocks before the current group
-        unsigned prog_seen[W - 1];
-#pragma unroll
-        for (int w = 0; w < W - 1; ++w) prog_seen[w] = 0;
-        bool ok = true;
-        for (int k = 0; k < nb && ok; ++k) {
-            // the buffer of tile k-1 is free now (this wave was its last reader): stage tile k+1, prefetch k+2
-            if (k + 1 < nb) {
-                store_tile(k + 1, n0, n1);
-                if (k + 2 < nb) load_tile(k + 2, n0, n1);
-            }
-            const long long st = tile_start(k);
-            const bool bad_tile = (bad_bits[k / 32] >> (k % 32)) & 1u;
-            const bool fast_tile = k >= 1 && k <= nb - 2 && all_ok && !bad_tile;
-            if (!fast_tile) {
-                if (active) general(k, st, 0, kTile);
-            } else {
-                const Rec<T>* walk = &tile[k & 1][t];
-#pragma unroll 1
-                for (int jg = 0; jg < kBlocksPerTile && ok; jg += kGrp) {
-                    const unsigned g0 = gbase + jg;
-                    // (a) every producer block of the group must have been published
-                    unsigned u = nonchain;
-#pragma unroll
-                    for (int q = 0; q < kGrp; ++q) {
-                        if (chain_owns(g0 + q)) continue;
-                        const int pw = (int)(u % (W - 1));
-                        const unsigned need = u / (W - 1) + 1;
-                        ++u;
-                        unsigned seen = 0;
-#pragma unroll
-                        for (int w = 0; w < W - 1; ++w) if (w == pw) seen = prog_seen[w];
-                        if ((int)(seen - need) < 0) {
-                            ok = ok && ring_wait(&sync.prog[pw], need, &sync.abort);
-                            seen = lds_load_acquire(&sync.prog[pw]);
-#pragma unroll
-                            for (int w = 0; w < W - 1; ++w) if (w == pw) prog_seen[w] = seen;
-                        }
-                    }
-                    if (!ok) break;
-                    // (b) all term reads of the group back to back
-                    Term2 tm[kGrp][kRB / 2];
-                    unsigned long long fm[kGrp];
-#pragma unroll
-                    for (int q = 0; q < kGrp; ++q) {
-                        fm[q] = 0;
-                        if (chain_owns(g0 + q)) continue;
-                        const int slot = (int)((g0 + q) % kSlots);
-                        fm[q] = ring_flag[slot];
-#pragma unroll
-                        for (int r = 0; r < kRB / 2; ++r) tm[q][r] = ring[slot][r][l];
-                    }
-                    // (c) the adds, strictly in walk order
-#pragma unroll
-                    for (int q = 0; q < kGrp; ++q) {
-                        const int o0 = (jg + q) * kRB;
-                        const float fx0 = a.fx, fy0 = a.fy;
-                        float fx = fx0, fy = fy0;
-                        if (chain_owns(g0 + q)) {
-                            unsigned long long flag = 0;
-#pragma unroll
-                            for (int r = 0; r < kRB; ++r) {
-                                float tx, ty;
-                                term(walk[o0 + r], flag, tx, ty);
-                                fx = fx + tx;
-                                fy = fy + ty;
-                            }
-                            fm[q] = flag != 0ull ? ~0ull : 0ull;
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < kRB / 2; ++r) {
-                                fx = fx + tm[q][r].x0; fy = fy + tm[q][r].y0;
-                                fx = fx + tm[q][r].x1; fy = fy + tm[q][r].y1;
-                            }
-                            ++nonchain;
-                        }
-                        a.fx = fx; a.fy = fy;
-                        if (fm[q] != 0ull) {
-                            if (((fm[q] >> l) & 1ull) && active) {
-                                a.fx = fx0; a.fy = fy0;
-                                general(k, st, o0, o0 + kRB);
-                            }
-                        }
-                    }
-                    if (l == 0) lds_store_release(&sync.consumed, g0 + kGrp);
-                }
-                gbase += kBlocksPerTile;
-            }
-            if (active) {
-                const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;
-                pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
-            }
-        }
-        if (!ok && l == 0) atomicAdd(&ctr->errors, 1ull);
-        if (mine) {
-            const int q = i - lo;
-            if (active) {
-                Rec<T> out; Vec2<T> vout;
-                finish_body<T>(a, v, p, out, vout);
-                S_J[q] = out;
-                S_V[q] = vout;
-            } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
-                S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
-                S_V[q] = v;
-            }
-        }
-        for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
-        if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
-    } else {
-        // =================================== producer wave ==================================================
-        const int me = wave - 1;
-        bool ok = ring_wait(&sync.tile_ready, 1u, &sync.abort);   // wg_bad is final once a tile is published
-        const bool all_ok = lds_load_acquire(&sync.wg_bad) == 0u;
-        unsigned gbase = 0, nonchain = 0, mine_done = 0, consumed_seen = 0;
-        for (int k = 1; k <= nb - 2 && ok && all_ok; ++k) {
-            ok = ring_wait(&sync.tile_ready, (unsigned)(k + 1), &sync.abort);
-            if (!ok) break;
-            if ((bad_bits[k / 32] >> (k % 32)) & 1u) continue;    // the chain wave does this tile alone
-            const Rec<T>* walk = &tile[k & 1][t];
-#pragma unroll 1
-            for (int j = 0; j < kBlocksPerTile; ++j) {
-                const unsigned g = gbase + j;
-                if (chain_owns(g)) continue;
-                const unsigned u = nonchain++;
-                if ((int)(u % (W - 1)) != me) continue;
-                // slot g mod kSlots is free once the chain wave is done with block g - kSlots
-                if (g >= (unsigned)kSlots && (int)(consumed_seen - (g - kSlots + 1)) < 0) {
-                    ok = ring_wait(&sync.consumed, g - kSlots + 1, &sync.abort);
-                    if (!ok) break;
-                    consumed_seen = lds_load_acquire(&sync.consumed);
-                }
-                const int slot = (int)(g % kSlots);
-                unsigned long long flag = 0;
-#pragma unroll
-                for (int r = 0; r < kRB; r += 2) {
-                    Term2 tm;
-                    term(walk[j * kRB + r], flag, tm.x0, tm.y0);
-                    term(walk[j * kRB + r + 1], flag, tm.x1, tm.y1);
-                    ring[slot][r / 2][l] = tm;
-                }
-                if (l == 0) ring_flag[slot] = flag;
-                ++mine_done;
-                if (l == 0) lds_store_release(&sync.prog[me], mine_done);
-            }
-            if (!ok) break;
-            gbase += kBlocksPerTile;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Stable compaction of the own range on `mass != 0` (src/nbody.cu:488-510), two small kernels.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCompactBlock = 1024;
