@@ -169,6 +169,9 @@ int nbody_step(nbody_ctx* ctx, int nsteps);
 int nbody_download(nbody_ctx* ctx, void* block, int* n);
 int nbody_body_count(nbody_ctx* ctx, int* n);   /* synchronises */
 int nbody_sync(nbody_ctx* ctx);                 /* CUDA_SYNC_CHECK (src/nbody.cu:20-33,546)           */
+/* Context introspection used by the state files. */
+int nbody_ctx_info(nbody_ctx* ctx, nbody_ctx_desc* desc_out, int64_t* steps);
+int nbody_ctx_set_steps(nbody_ctx* ctx, int64_t steps);
 
 typedef struct nbody_event {  /* one collision event, in the index space of the step it happened in    */
     int32_t step;             /* step counter since upload (0-based)                                   */
@@ -193,6 +196,16 @@ typedef struct nbody_stats {
 int nbody_get_stats(nbody_ctx* ctx, nbody_stats* out);  /* synchronises */
 /* Bracket every force-kernel launch with HIP events on the context's stream (bench / profiling). */
 int nbody_set_kernel_timing(nbody_ctx* ctx, int enable);
+
+/* State dump / restore (the reference has none): a 64-byte header {magic "NBODYST1", precision,
+ * body count, steps since upload, timestep, growthRate, field} followed by the [P|V|M|R] block of the current
+ * survivors, i.e. exactly what nbody_download returns.  nbody_state_load uploads the block into ctx (which must
+ * have the same precision and enough capacity) and restores the step counter; parameters in the file are
+ * informational, the context keeps its own. */
+int nbody_state_save(nbody_ctx* ctx, const char* path);
+int nbody_state_load(nbody_ctx* ctx, const char* path);
+/* Reads only the header of a state file. Any output pointer may be NULL. */
+int nbody_state_peek(const char* path, int* precision, int* n, int64_t* steps);
 
 /* Multi-rank plumbing (world > 1).  One process per GPU; the host language moves the 128-byte id. */
 #define NBODY_COMM_ID_BYTES 128

@@ -107,6 +107,11 @@ SYMBOLS = {
     "nbody_clear_events": (_i, [_vp]),
     "nbody_get_stats": (_i, [_vp, ctypes.POINTER(Stats)]),
     "nbody_set_kernel_timing": (_i, [_vp, _i]),
+    "nbody_ctx_info": (_i, [_vp, ctypes.POINTER(_CtxDesc), ctypes.POINTER(ctypes.c_int64)]),
+    "nbody_ctx_set_steps": (_i, [_vp, ctypes.c_int64]),
+    "nbody_state_save": (_i, [_vp, ctypes.c_char_p]),
+    "nbody_state_load": (_i, [_vp, ctypes.c_char_p]),
+    "nbody_state_peek": (_i, [ctypes.c_char_p, _ip, _ip, ctypes.POINTER(ctypes.c_int64)]),
     "nbody_comm_unique_id": (_i, [_vp]),
     "nbody_group_step": (_i, [_pp, _i, _i]),
     "nbody_group_download": (_i, [_pp, _i, _vp, _ip]),
@@ -289,9 +294,15 @@ class Stepper:
         _check(lib.nbody_ctx_create(ctypes.byref(self._ctx), ctypes.byref(d)))
 
     def close(self):
-        if getattr(self, "_ctx", None):
+        if getattr(self, "_ctx", None) and lib is not None:     # `lib` is gone at interpreter shutdown
             lib.nbody_ctx_destroy(self._ctx)
             self._ctx = None
+
+    def save_state(self, path):
+        _check(lib.nbody_state_save(self._ctx, os.fsencode(path)))
+
+    def load_state(self, path):
+        _check(lib.nbody_state_load(self._ctx, os.fsencode(path)))
 
     __del__ = close
 

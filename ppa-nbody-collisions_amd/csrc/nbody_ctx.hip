@@ -231,7 +231,8 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //   below         : producer/consumer, 4 producer waves per chain wave
     if (c->own_upper >= 98304) launch_v3<1>(c, p, nblocks, log);
     else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
-    else launch_pc<1, 4, 32>(c, p, nblocks, log);
+    else if (c->desc.semantics == NBODY_LITERAL) launch_pc<1, 4, 32>(c, p, nblocks, log);
+    else launch_v3<4>(c, p, nblocks, log);                 // the pc kernel walks the literal tile order only
 }
 
 template <typename T>
@@ -346,8 +347,11 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad capacity/rank/world");
     if (d->precision != NBODY_F32 && d->precision != NBODY_F64)
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad precision");
-    if (d->semantics != NBODY_LITERAL)
-        return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: only NBODY_LITERAL semantics is built yet");
+    if (d->semantics != NBODY_LITERAL && d->semantics != NBODY_CLEAN)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad semantics");
+    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 &&
+        ((d->kernel_variant >= 2 && d->kernel_variant <= 4) || d->kernel_variant >= 20))
+        return nbody_fail(NBODY_ERR_INVALID, "kernel_variant %d implements the literal semantics only", d->kernel_variant);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -570,6 +574,26 @@ int nbody_sync(nbody_ctx* c) {
     HIP_TRY(hipSetDevice(c->desc.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_ctx_info(nbody_ctx* c, nbody_ctx_desc* desc_out, int64_t* steps) {
+    if (!c) return nbody_fail(NBODY_ERR_INVALID, "NULL context");
+    if (desc_out) *desc_out = c->desc;
+    if (steps) *steps = c->steps;
+    return NBODY_OK;
+}
+
+int nbody_ctx_set_steps(nbody_ctx* c, int64_t steps) {
+    if (!c || steps < 0 || steps > 0x7fffffff) return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_set_steps: bad argument");
+    if (!c->uploaded) return nbody_fail(NBODY_ERR_STATE, "nbody_ctx_set_steps before nbody_upload");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    int rc = read_meta(c);
+    if (rc != NBODY_OK) return rc;
+    c->h_meta->step = (int)steps;
+    HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->steps = steps;
     return NBODY_OK;
 }
 

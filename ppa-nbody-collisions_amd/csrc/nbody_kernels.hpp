@@ -154,12 +154,14 @@ __global__ __launch_bounds__(kTile) void forces_v1(const Rec<T>* __restrict__ J,
     const int b = lo / kTile + blockIdx.x;                 // reference block index
     const long long blk0 = (long long)b * kTile;
     if (blk0 >= (long long)lo + cnt) return;               // grid is sized for the capacity; whole-WG exit
-    const int i = (int)blk0 + t;
+    const long long i64 = blk0 + t;
+    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
     const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool mine = i >= lo && i < lo + cnt;
+    const bool lit = p.literal != 0;                       // else NBODY_CLEAN: see forces_v3_f32
+    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
+    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
     // literal: only bodies with a thread are updated (quirk Q2); N < 128: the single block is guarded by i < N
-    const bool active = mine && i < N && (long long)i < (long long)nb * kTile;
-    const bool loader = i < N || N >= kTile;               // N < 128: lanes >= N load nothing (:143)
+    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
 
     BodyAcc<T> a;
     Vec2<T> v{0, 0};
@@ -173,46 +175,52 @@ __global__ __launch_bounds__(kTile) void forces_v1(const Rec<T>* __restrict__ J,
     a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
     unsigned long long pairs = 0;
 
-    // prologue: tile 0
-    {
-        long long src = blk0 + t;                          // (i + 128*0) % N
+    long long start = lit ? blk0 % N : 0;
+    auto entry_index = [&](long long st) -> int {          // this lane's entry of the tile starting at st, or -1
+        long long src = st + t;
+        if (!lit) return src < N ? (int)src : -1;
+        if (N < kTile && t >= N) return -1;                // lanes >= N load nothing (:143)
+        if (src >= N) src -= N;
         if (src >= N) src %= N;
-        if (loader) tile[0][t] = J[src];
+        return (int)src;                                   // :186
+    };
+    {
+        const int e = entry_index(start);
+        if (e >= 0) tile[0][t] = J[e];
     }
     __syncthreads();
-    for (int k = 0; k < nb; ++k) {
+    for (int k = 0; k < ntiles; ++k) {
         const int cur = k & 1;
         // prefetch tile k+1 into registers while tile k is consumed
-        Rec<T> nxt;
-        const bool have_next = (k + 1 < nb);
-        if (have_next && loader) {
-            long long src = blk0 + (long long)kTile * (k + 1) + t;    // :186
-            if (src >= N) src %= N;
-            nxt = J[src];
-        }
-        const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;        // :194 (quirk Q1)
+        Rec<T> nxt{};
+        const bool have_next = (k + 1 < ntiles);
+        long long next_start = start + kTile;
+        if (lit) while (next_start >= N) next_start -= N;
+        const int e_next = have_next ? entry_index(next_start) : -1;
+        if (e_next >= 0) nxt = J[e_next];
+        int L;
+        if (lit) L = (k == nb - 1) ? N % (kTile + 1) : kTile;                 // :194 (quirk Q1)
+        else L = (N - start) < kTile ? (int)(N - start) : kTile;
         if (active) {
-            const long long base = blk0 + (long long)kTile * k;
-            if (L == kTile) {
-                for (int off = (k == 0 ? 1 : 0); off < kTile; ++off) {   // :200-204 skip (k=0, off=0)
-                    const int s = (t + off) & (kTile - 1);                // :207
-                    long long j = base + s;
-                    if (j >= N) j %= N;
-                    interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-                }
-                pairs += (k == 0) ? kTile - 1 : kTile;
-            } else {
-                for (int off = (k == 0 ? 1 : 0); off < L; ++off) {
-                    const int s = (t + off) % L;
-                    long long j = base + s;
+            if (lit) {
+                for (int off = (k == 0 ? 1 : 0); off < L; ++off) {           // :200-204 skip (k=0, off=0)
+                    const int s = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L);   // :207
+                    long long j = start + s;
                     if (j >= N) j %= N;
                     interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
                 }
                 pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+            } else {
+                for (int off = 0; off < L; ++off) {
+                    if (start + off == i64) continue;
+                    interact<T, kLog>(a, tile[cur][off], p.growth, i, (int)(start + off), ev, ev_cap, ctr, step);
+                }
+                pairs += L - ((i64 >= start && i64 < start + L) ? 1 : 0);
             }
         }
-        if (have_next && loader) tile[cur ^ 1][t] = nxt;
+        if (e_next >= 0) tile[cur ^ 1][t] = nxt;
         __syncthreads();
+        start = next_start;
     }
 
     if (mine) {
@@ -486,12 +494,15 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
     const long long blk0 = (long long)b * kTile;
     if (blk0 + (wg % K) * kBodies >= (long long)lo + cnt) return;
     const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool loader = lane < N || N >= kTile;            // N < 128: lanes >= N load nothing (:143)
+    // clean semantics (NBODY_CLEAN): every body active, tiles are the plain index ranges 128k..128k+127 in
+    // ascending order, every lane walks a tile from its entry 0, the body itself is skipped by index
+    const bool lit = p.literal != 0;
+    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
 
     const long long i64 = blk0 + t;
     const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
     const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && i64 < (long long)nb * kTile;
+    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
     const bool chain = h == 0;                             // lane that owns the accumulators
     BodyAcc<T> a;
     Vec2<T> v{0, 0};
@@ -509,9 +520,12 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
     const bool wave_r0 = __ballot(active && __float_as_uint(a.ri) != 0u) == 0ull;
     unsigned long long pairs = 0;
 
-    long long start = blk0 % N;                            // first body of the current tile (cyclic)
+    long long start = lit ? blk0 % N : 0;                  // first body of the current tile
+    // lane's entry of the tile starting at body st, or -1 if it has none (N < 128 literal :143; clean tail)
     auto entry_index = [&](long long st) -> int {
         long long src = st + lane;
+        if (!lit) return src < N ? (int)src : -1;
+        if (N < kTile && lane >= N) return -1;
         if (src >= N) src -= N;
         if (src >= N) src %= N;                            // only when N < 128
         return (int)src;
@@ -521,39 +535,53 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
     };
     {
         Rec<T> r{0, 0, 0, 0};
-        if (loader) { r = J[entry_index(start)]; tile[0][lane] = r; tile[0][lane + kTile] = r; }
-        const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
-        const bool rnz = __ballot(loader && __float_as_uint(r.r) != 0u) != 0ull;
+        const int e = entry_index(start);
+        if (e >= 0) { r = J[e]; tile[0][lane] = r; tile[0][lane + kTile] = r; }
+        const bool bad = __ballot(e >= 0 && coord_bad(r)) != 0ull;
+        const bool rnz = __ballot(e >= 0 && __float_as_uint(r.r) != 0u) != 0ull;
         if ((lane & (kWave - 1)) == 0) { tile_bad[0][wave] = bad; tile_rnz[0][wave] = rnz; }
     }
     __syncthreads();
 
-    for (int k = 0; k < nb; ++k) {                         // :182, tile k of this body = cyclic tile b + k
+    for (int k = 0; k < ntiles; ++k) {                     // :182, literal: tile k of this body = cyclic tile b + k
         const int cur = k & 1;
-        const bool have_next = k + 1 < nb;
+        const bool have_next = k + 1 < ntiles;
         long long next_start = start + kTile;
-        while (next_start >= N) next_start -= N;
+        if (lit) while (next_start >= N) next_start -= N;
         Rec<T> nxt{0, 0, 0, 0};
-        if (have_next && loader) nxt = J[entry_index(next_start)];
+        const int e_next = have_next ? entry_index(next_start) : -1;
+        if (e_next >= 0) nxt = J[e_next];
 
-        const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;                // :194 (quirk Q1)
+        int L;
+        if (lit) L = (k == nb - 1) ? N % (kTile + 1) : kTile;                 // :194 (quirk Q1)
+        else L = (N - start) < kTile ? (int)(N - start) : kTile;
         // general code on walk positions [o0, o1) of this tile, by the chain lane, exact for every input
         auto general = [&](int o0, int o1) {
             if (!(active && chain)) return;
-            for (int off = o0; off < o1; ++off) {
-                if (k == 0 && off == 0) continue;                              // :200-204
-                const int s = (L == kTile) ? (t + off) : ((t + off) % L);      // :207 (doubled tile: no wrap)
-                long long j = start + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
-                if (j >= N) j %= N;
+            const int hi = o1 < L ? o1 : L;
+            for (int off = o0; off < hi; ++off) {
+                int s;
+                long long j;
+                if (lit) {
+                    if (k == 0 && off == 0) continue;                          // :200-204
+                    s = (L == kTile) ? (t + off) : ((t + off) % L);            // :207 (doubled tile: no wrap)
+                    j = start + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
+                    if (j >= N) j %= N;
+                } else {
+                    s = off;
+                    j = start + off;
+                    if (j == i64) continue;
+                }
                 interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
             }
         };
         bool bad_tile = false;
 #pragma unroll
         for (int w = 0; w < kTile / kWave; ++w) bad_tile = bad_tile || tile_bad[cur][w] != 0;
-        const bool interior = k >= 1 && k <= nb - 2;
+        // tiles whose every position is an ordinary pair for every lane of the workgroup
+        const bool interior = lit ? (k >= 1 && k <= nb - 2) : (L == kTile && k != b);
         if (interior && wave_ok && !bad_tile) {
-            const Rec<T>* walk = &tile[cur][t + h];        // entry of walk position off = h
+            const Rec<T>* walk = &tile[cur][(lit ? t : 0) + h];   // entry of walk position off = h
             bool rnz_tile = false;
 #pragma unroll
             for (int w = 0; w < kTile / kWave; ++w) rnz_tile = rnz_tile || tile_rnz[cur][w] != 0;
@@ -604,11 +632,14 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
         } else {
             general(0, L);
         }
-        if (active && chain) pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+        if (active && chain) {
+            if (lit) pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+            else pairs += L - ((i64 >= start && i64 < start + L) ? 1 : 0);
+        }
         if (have_next) {
-            if (loader) { tile[cur ^ 1][lane] = nxt; tile[cur ^ 1][lane + kTile] = nxt; }
-            const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
-            const bool rnz = __ballot(loader && __float_as_uint(nxt.r) != 0u) != 0ull;
+            if (e_next >= 0) { tile[cur ^ 1][lane] = nxt; tile[cur ^ 1][lane + kTile] = nxt; }
+            const bool bad = __ballot(e_next >= 0 && coord_bad(nxt)) != 0ull;
+            const bool rnz = __ballot(e_next >= 0 && __float_as_uint(nxt.r) != 0u) != 0ull;
             if ((lane & (kWave - 1)) == 0) { tile_bad[cur ^ 1][wave] = bad; tile_rnz[cur ^ 1][wave] = rnz; }
         }
         __syncthreads();

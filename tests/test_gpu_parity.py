@@ -244,6 +244,76 @@ def test_reference_shaped_launches(nb):
         dev = torch.from_numpy(blk[:6 * n].copy()).cuda()
 
 
+@pytest.mark.parametrize("variant", [0, 1, 11, 12, 14, 18])
+@pytest.mark.parametrize("n,field,steps", [(1000, 5000, 6), (1024, 5000, 6), (130, 1500, 5), (77, 1000, 5),
+                                           (4096, 100000, 2)])
+def test_clean_semantics_matches_oracle(nb, n, field, steps, variant):
+    """NBODY_CLEAN: every body active, all pairs, ascending j.  No reference exists for it (it is
+    what the reference was meant to compute): checked bit-exactly against the oracle's clean mode."""
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field)
+    bodies = nb.init_bodies(cfg)
+    st = nb.Stepper(cfg, semantics=nb.CLEAN, record_events=True, kernel_variant=variant)
+    st.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    pairs = 0
+    for s in range(steps):
+        st.step(1)
+        pairs += cur * (cur - 1)
+        cur, stats, ab, de, _ = ol.port_step(blk, cur, DT, field, field, GROWTH, semantics=ol.CLEAN)
+        ev = st.events()
+        ev = ev[ev["step"] == s]
+        assert sorted((int(e["i"]), int(e["j"])) for e in ev[ev["kind"] == 0]) == \
+            sorted((int(x), int(y)) for x, y in ab), "E_t step %d" % s
+        assert_bodies_equal(st.download(), blk, cur, "clean step %d" % s)
+    assert st.stats().pairs == pairs
+    st.close()
+
+
+def test_clean_semantics_sharded_and_fp64(nb):
+    cfg = nb.stock_config(particleCount=900, fieldWidth=4000, fieldHeight=4000)
+    for precision, dt, gr in ((nb.F32, DT, GROWTH), (nb.F64, float(DT), float(GROWTH))):
+        bodies = nb.init_bodies(cfg, precision)
+        grp = nb.StepperGroup(3, cfg=cfg, precision=precision, semantics=nb.CLEAN)
+        grp.upload(bodies)
+        grp.step(5)
+        blk = bodies.contiguousData.copy()
+        cur = 900
+        for s in range(5):
+            cur, *_ = ol.port_step(blk, cur, dt, 4000, 4000, gr, semantics=ol.CLEAN, want_events=False)
+        out = grp.download()
+        assert out.numBodies == cur and cur < 900
+        assert np.array_equal(bits(out.block), bits(blk[:6 * cur]))
+        grp.close()
+
+
+def test_state_save_restore(nb, tmp_path):
+    """Dump after 3 steps, restore into a fresh context, continue: same bits as the uninterrupted run; the dump's
+    payload is the reference block layout of the survivors."""
+    z = np.load(os.path.join(GOLD, "steps_dense_n1024.npz"))
+    dt, growth, fw, fh = z["params"]
+    mk = lambda: nb.Stepper(capacity=1024, timestep=float(dt), growthRate=float(growth), fieldWidth=int(fw),
+                            fieldHeight=int(fh), record_events=True)
+    a = mk()
+    a.upload(nb.BodiesData.from_block(z["init"].view(np.float32), 1024))
+    a.step(3)
+    path = str(tmp_path / "state.bin")
+    a.save_state(path)
+    prec, n, steps = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    assert nb.lib.nbody_state_peek(os.fsencode(path), ctypes.byref(prec), ctypes.byref(n), ctypes.byref(steps)) == 0
+    assert (prec.value, n.value, steps.value) == (nb.F32, int(z["counts"][2]), 3)
+    raw = np.fromfile(path, dtype=np.uint32, offset=64)
+    assert np.array_equal(raw, bits(a.download().block))
+    b = mk()
+    b.load_state(path)
+    a.step(2)
+    b.step(2)
+    assert_bodies_equal(b.download(), z["after_5"].view(np.float32), int(z["counts"][4]), "restored run")
+    assert_bodies_equal(a.download(), z["after_5"].view(np.float32), int(z["counts"][4]), "uninterrupted run")
+    assert set(b.events()["step"]) <= {3, 4}          # the step counter was restored too
+    a.close(); b.close()
+
+
 def test_fp64_matches_oracle(nb):
     """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); the HIP path is
     checked bit-exactly against the fp64 instantiation of the oracle."""
