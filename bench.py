@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="take the multi-rank code path (rendezvous, RCCL communicator, slot all-gather) even "
+                         "with one rank; used to rehearse the N>1 launch on a 1-GPU box")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,7 +96,7 @@ def main():
 
     comm_id = None
     dist = None
-    if world > 1:
+    if world > 1 or (a.force_comm and "RANK" in os.environ):
         import torch.distributed as dist
         dist.init_process_group(backend="gloo")
         torch.cuda.set_device(local_rank)
@@ -107,8 +110,10 @@ def main():
     kw = {} if a.stock_radii else {"minRadius": 0.0, "maxRadius": 0.0}
     cfg = nb.stock_config(particleCount=a.bodies, totalIterations=a.steps, **kw)
     bodies = nb.init_bodies(cfg, precision)
+    if a.force_comm and comm_id is None:
+        comm_id = nb.comm_unique_id()
     st = nb.Stepper(cfg, precision=precision, device=local_rank, rank=rank, world=world, comm_id=comm_id,
-                    kernel_variant=a.variant)
+                    kernel_variant=a.variant, force_comm=a.force_comm)
     st.upload(bodies)
 
     def barrier():

@@ -314,6 +314,45 @@ def test_state_save_restore(nb, tmp_path):
     a.close(); b.close()
 
 
+def test_bench_distributed_control_path_one_rank():
+    """bench.py exactly as the driver launches it for N>1 (torch.distributed.run, gloo rendezvous on 127.0.0.1,
+    communicator id broadcast, RCCL slot all-gather), rehearsed with ONE rank because the box has one GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--bodies", "16384", "--force-comm", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["roofline"]["kernel_ms"] > 0
+
+
+def test_cli_matches_oracle(nb, tmp_path):
+    """The `nbody` command-line driver (C host code over the C ABI): reads ./nbodyConfig.txt from the current
+    directory like the reference binary, echoes it, steps, and (--dump) emits the survivors' block."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ppa-nbody-collisions_amd", "nbody")
+    cfg = nb.stock_config(particleCount=1500, totalIterations=7, fieldWidth=6000, fieldHeight=6000)
+    nb.write_config(str(tmp_path / "nbodyConfig.txt"), cfg)
+    r = subprocess.run([exe, "--dump"], cwd=str(tmp_path), capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    blk = nb.init_bodies(cfg).contiguousData.copy()
+    n = 1500
+    for s in range(7):
+        n, *_ = ol.port_step(blk, n, DT, 6000, 6000, GROWTH, want_events=False)
+    head, _, rest = out.partition(b"=====================\n")
+    assert head.startswith(b"Running simulation with the following settings:\nparticleCount=1500\n")
+    assert (b"Bodies left: %d\n" % n) in rest
+    marker = rest.index(b"body-pair-interactions/sec\n") + len(b"body-pair-interactions/sec\n")
+    payload = rest[marker:marker + 24 * n]
+    assert np.array_equal(np.frombuffer(payload, dtype=np.uint32), blk[:6 * n].view(np.uint32))
+
+
 def test_fp64_matches_oracle(nb):
     """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); the HIP path is
     checked bit-exactly against the fp64 instantiation of the oracle."""
