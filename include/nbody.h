@@ -197,6 +197,15 @@ int nbody_get_stats(nbody_ctx* ctx, nbody_stats* out);  /* synchronises */
 /* Bracket every force-kernel launch with HIP events on the context's stream (bench / profiling). */
 int nbody_set_kernel_timing(nbody_ctx* ctx, int enable);
 
+/* Image output.  nbody_render_image = cudaMemsetAsync(254) + generateImage + D2H
+ * (src/nbody.cu:531-537, kernel :294-348): bodies drawn as filled discs of value 0 into img[width*height]; the
+ * kernel's missing `i < numBodies` guard is present.  On a multi-rank context every rank can render (the
+ * replica holds all positions and radii).  nbody_write_pgm = saveImageToDisk (:350-371): prints
+ * "Saving (WxH) to disk", writes "P5\nW H\n255\n" + bytes; where the reference prints its error and exit(1)s
+ * it prints the same text to stderr and returns NBODY_ERR_IO. */
+int nbody_render_image(nbody_ctx* ctx, unsigned char* img, int width, int height);
+int nbody_write_pgm(const char* path, const unsigned char* img, int width, int height);
+
 /* State dump / restore (the reference has none): a 64-byte header {magic "NBODYST1", precision,
  * body count, steps since upload, timestep, growthRate, field} followed by the [P|V|M|R] block of the current
  * survivors, i.e. exactly what nbody_download returns.  nbody_state_load uploads the block into ctx (which must

@@ -32,6 +32,32 @@ static int oracle_active_count(int n, int semantics) {
 #undef FN
 #undef RSQRT_
 
+void oracle_render_f32(const void* block, int n, int blocks, unsigned char* img, int w, int h, int fieldW,
+                       int fieldH) {
+    const float* P = (const float*)block;
+    const float* R = P + 5 * (size_t)n;
+    memset(img, 254, (size_t)w * h);                                   /* src/nbody.cu:534 */
+    const int img_width = w, img_height = h;
+    const int doubleFieldWidth = fieldW << 1, doubleFieldHeight = fieldH << 1;   /* :314-315 */
+    const long long lim = (long long)blocks * 128;
+    for (int i = 0; i < n && i < lim; ++i) {
+        const float px = P[2 * i], py = P[2 * i + 1];
+        const float r = (R[i] * w) / fieldW;                            /* :310 */
+        const int xc = (int)(((px + fieldW) / doubleFieldWidth) * img_width);    /* :318 */
+        const int yc = (int)(((py + fieldH) / doubleFieldHeight) * img_height);  /* :319 */
+        const int y_min = yc - r < 0 ? 0 : yc - r;                      /* :323 */
+        const int y_max = yc + r >= img_height ? img_height : yc + r;   /* :324 */
+        const int x_min = xc - r < 0 ? 0 : xc - r;                      /* :325 */
+        const int x_max = xc + r > img_width ? img_width : xc + r;      /* :326 */
+        for (int y = y_min; y < y_max; ++y) {                           /* :328 (the clamps at :330-331,334-335 */
+            for (int x = x_min; x < x_max; ++x) {                       /*  cannot fire inside these bounds)    */
+                const int x_sq = (x - xc) * (x - xc), y_sq = (y - yc) * (y - yc);   /* :336-337 */
+                if (x_sq + y_sq <= (int)(r * r)) img[(size_t)img_width * y + x] = 0; /* :338-344 */
+            }
+        }
+    }
+}
+
 int oracle_jlist(int n, int i, int semantics, int32_t* out) {
     if (n <= 0 || i < 0 || i >= n || !out) return -1;
     if (i >= oracle_active_count(n, semantics)) return -1;

@@ -11,7 +11,7 @@
  * Pinning: the reference holds no tests or golden vectors.  This restatement is pinned
  * against the reference ITSELF: oracle/_ref/libnbody_ref.so runs the reference's own kernel text on the CPU
  * (oracle/ref_shim), tests/golden/ holds vectors generated from it (tests/golden/make_golden.py), and
- * tests/test_oracle_vs_ref.py checks bit-equality of this file against both.  The fp64 variant has no
+ * tests/test_oracle_cpu.py checks bit-equality of this file against both.  The fp64 variant has no
  * reference at all (the reference has no fp64 kernel): "parity unpinned" for fp64.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
@@ -58,6 +58,12 @@ int oracle_range_f32(const void* block, int n, int lo, int hi, float dt, int fie
 int oracle_range_f64(const void* block, int n, int lo, int hi, double dt, int fieldW, int fieldH,
                      double growth, int semantics, double* outP, double* outV, double* outM, double* outR,
                      uint8_t* del_flags, oracle_stats* stats);
+
+/* generateImage (src/nbody.cu:294-348) with the missing `i < numBodies` guard: bodies i < min(n, blocks*128) are
+ * rasterised as filled discs (value 0) into img[w*h], pre-set to 254 (:534).  `blocks` is the block count of the
+ * launch (:535 passes the stale count of the step that produced the block).  fp32 arithmetic as written. */
+void oracle_render_f32(const void* block, int n, int blocks, unsigned char* img, int w, int h, int fieldW,
+                       int fieldH);
 
 /* Number of ordered pairs the stepper evaluates in one step at body count n. */
 int64_t oracle_pairs_per_step(int n, int semantics);

@@ -1,7 +1,7 @@
 // oracle/ref_shim/ref_shim.cpp -- TEST INFRASTRUCTURE, not product code.
 //
 // "Literal oracle": runs the reference's OWN device code (predicate + ComputeForces + MoveBodies,
-// /root/reference/src/nbody.cu:126-292) on the CPU, unmodified.  The kernel text is sliced out of the
+// generateImage, /root/reference/src/nbody.cu:126-348) on the CPU, unmodified.  The kernel text is sliced out of the
 // reference by line range AT BUILD TIME into a temporary file (see oracle/Makefile; the slice never enters
 // this repository and is deleted after the build) and #included below as REF_SLICE.  The reference's own
 // headers (vec2f.h, jbutil.h, nbodyConfig.h) are included from /root/reference/include by -I.
@@ -44,7 +44,7 @@ thread_local Vec2f sharedMem[2048];
 
 static void __syncthreads();
 
-#include REF_SLICE   // /root/reference/src/nbody.cu lines 126-292, verbatim, from a temp file
+#include REF_SLICE   // /root/reference/src/nbody.cu lines 126-348, verbatim, from a temp file
 
 // ------------------------------------------------------------------------------------------------------
 // fiber scheduler
@@ -114,6 +114,15 @@ void forces_body(void* p) {
     // updatedVelocities is a never-allocated pointer in the reference (src/nbody.cu:441,482) and unused
     ComputeForces(a->bodyData, a->updM, (Vec2f*)nullptr, a->updR, a->n, a->dt, a->fw, a->fh, a->nb, a->growth);
 }
+struct ImageArgs { void* bodyData; int n; char* img; int w, h, fw, fh; };
+void image_body(void* p) {
+    ImageArgs* a = (ImageArgs*)p;
+    // the reference kernel has no `i < numBodies` guard (src/nbody.cu:302-310) and is launched with a stale
+    // block count (:535): threads past the body count read out of bounds there.  The shim only runs threads
+    // that have a body, which is the guarded behaviour SURVEY.md 8 f3 asks for.
+    if ((int)(blockIdx.x * blockDim.x + threadIdx.x) >= a->n) return;
+    generateImage(a->bodyData, a->n, a->img, a->w, a->h, a->fw, a->fh);
+}
 struct MoveArgs { void* bodyData; float* updM; float* updR; int n; float dt; };
 void move_body(void* p) {
     MoveArgs* a = (MoveArgs*)p;
@@ -168,6 +177,15 @@ int ref_step(void* block, int* n, float dt, int fieldW, int fieldH, float growth
     memcpy(block, tmp.data(), (size_t)newN * 24);
     *n = newN;
     return 0;
+}
+
+// generateImage (src/nbody.cu:294-348) on a host block of n bodies, launched with `blocks` blocks of 128 threads
+// as at :535 (the caller passes the STALE block count of the step that produced the block); the image is
+// pre-set to 254 as cudaMemsetAsync does at :534.
+void ref_render(void* block, int n, int blocks, char* img, int w, int h, int fieldW, int fieldH) {
+    memset(img, 254, (size_t)w * h);
+    ImageArgs ia{block, n, img, w, h, fieldW, fieldH};
+    for (int b = 0; b < blocks; ++b) run_block((unsigned)b, THREADS_PER_BLOCK, image_body, &ia);
 }
 
 // Initial conditions exactly as src/nbody.cu:401-416 (seed 1024, draws x,y,m,r per body, v = 0).

@@ -107,6 +107,8 @@ SYMBOLS = {
     "nbody_clear_events": (_i, [_vp]),
     "nbody_get_stats": (_i, [_vp, ctypes.POINTER(Stats)]),
     "nbody_set_kernel_timing": (_i, [_vp, _i]),
+    "nbody_render_image": (_i, [_vp, _vp, _i, _i]),
+    "nbody_write_pgm": (_i, [ctypes.c_char_p, _vp, _i, _i]),
     "nbody_ctx_info": (_i, [_vp, ctypes.POINTER(_CtxDesc), ctypes.POINTER(ctypes.c_int64)]),
     "nbody_ctx_set_steps": (_i, [_vp, ctypes.c_int64]),
     "nbody_state_save": (_i, [_vp, ctypes.c_char_p]),
@@ -259,6 +261,12 @@ def init_bodies(cfg, precision=F32):
 # ---------------------------------------------------------------------------------------------------------
 # device stepper
 # ---------------------------------------------------------------------------------------------------------
+def saveImageToDisk(filename, img):
+    """saveImageToDisk, src/nbody.cu:350-371 (binary PGM)."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    _check(lib.nbody_write_pgm(os.fsencode(filename), img.ctypes.data, img.shape[1], img.shape[0]))
+
+
 def comm_unique_id():
     buf = ctypes.create_string_buffer(COMM_ID_BYTES)
     _check(lib.nbody_comm_unique_id(buf))
@@ -297,6 +305,12 @@ class Stepper:
         if getattr(self, "_ctx", None) and lib is not None:     # `lib` is gone at interpreter shutdown
             lib.nbody_ctx_destroy(self._ctx)
             self._ctx = None
+
+    def render_image(self, width, height):
+        """cudaMemset(254) + generateImage + D2H, src/nbody.cu:531-537."""
+        img = np.zeros((height, width), dtype=np.uint8)
+        _check(lib.nbody_render_image(self._ctx, img.ctypes.data, width, height))
+        return img
 
     def save_state(self, path):
         _check(lib.nbody_state_save(self._ctx, os.fsencode(path)))

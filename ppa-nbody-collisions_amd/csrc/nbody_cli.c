@@ -1,7 +1,10 @@
 /* csrc/nbody_cli.c -- `nbody`: command-line driver with the reference binary's behaviour on the hot path
  * (main(), src/nbody.cu:373-551): reads ./nbodyConfig.txt from the current directory (:377), echoes the
  * settings, seeds the bodies (:401-416), runs totalIterations steps and prints the elapsed time (:548).
- * Image output (:512-539) is outside the hot path and not produced.  Host code in C over the C ABI. */
+ * Image output (:512-539) is produced with --images: iteration_<k>.ppm in cfg.imagePath for every k that is a
+ * multiple of save_Image_Every_Xth_Iteration and not the last iteration (the reference saves the image of
+ * iteration k during iteration k+1, :513-522, so the last one is never written).  Without --images the run is
+ * the pure stepping loop.  Host code in C over the C ABI. */
 #include "nbody.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -21,13 +24,14 @@ static int die(const char* what, int rc) {
 
 int main(int argc, char** argv) {
     const char* path = "nbodyConfig.txt";
-    int precision = NBODY_F32, gpus = 1, dump = 0;
+    int precision = NBODY_F32, gpus = 1, dump = 0, images = 0;
     for (int a = 1; a < argc; ++a) {
         if (!strcmp(argv[a], "--config") && a + 1 < argc) path = argv[++a];
         else if (!strcmp(argv[a], "--fp64")) precision = NBODY_F64;
         else if (!strcmp(argv[a], "--gpus") && a + 1 < argc) gpus = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--dump")) dump = 1;
-        else { fprintf(stderr, "usage: nbody [--config FILE] [--fp64] [--gpus N] [--dump]\n"); return 2; }
+        else if (!strcmp(argv[a], "--images")) images = 1;
+        else { fprintf(stderr, "usage: nbody [--config FILE] [--fp64] [--gpus N] [--dump] [--images]\n"); return 2; }
     }
     if (gpus < 1 || gpus > 64) return 2;
     double startTime = now();
@@ -54,8 +58,31 @@ int main(int argc, char** argv) {
         if (rc != NBODY_OK) return die("upload", rc);
     }
     double t0 = now();
-    rc = nbody_group_step(ctxs, gpus, cfg.totalIterations);
-    if (rc != NBODY_OK) return die("step", rc);
+    if (!images || cfg.save_Image_Every_Xth_Iteration <= 0) {
+        rc = nbody_group_step(ctxs, gpus, cfg.totalIterations);
+        if (rc != NBODY_OK) return die("step", rc);
+    } else {
+        unsigned char* img = (unsigned char*)malloc((size_t)cfg.imgWidth * cfg.imgHeight);
+        if (!img) return die("image alloc", NBODY_ERR_NOMEM);
+        int done = 0;
+        while (done < cfg.totalIterations) {
+            /* next iteration whose image the reference would save: k % every == 0 and k + 1 < totalIterations */
+            int k = ((done + cfg.save_Image_Every_Xth_Iteration - 1) / cfg.save_Image_Every_Xth_Iteration) *
+                    cfg.save_Image_Every_Xth_Iteration;
+            int upto = (k + 1 < cfg.totalIterations) ? k + 1 : cfg.totalIterations;
+            rc = nbody_group_step(ctxs, gpus, upto - done);
+            if (rc != NBODY_OK) return die("step", rc);
+            done = upto;
+            if (k + 1 < cfg.totalIterations && done == k + 1) {
+                char name[NBODY_IMAGE_PATH_MAX + 64];
+                rc = nbody_render_image(ctxs[0], img, cfg.imgWidth, cfg.imgHeight);
+                if (rc != NBODY_OK) return die("render", rc);
+                snprintf(name, sizeof(name), "%s/iteration_%d.ppm", cfg.imagePath, k);      /* :518 */
+                if (nbody_write_pgm(name, img, cfg.imgWidth, cfg.imgHeight) != NBODY_OK) return 1;   /* :369 */
+            }
+        }
+        free(img);
+    }
     int n = 0;
     rc = nbody_group_download(ctxs, gpus, block, &n);
     if (rc != NBODY_OK) return die("download", rc);

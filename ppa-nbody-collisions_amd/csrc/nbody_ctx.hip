@@ -108,6 +108,8 @@ struct nbody_ctx {
     Counters* counters = nullptr;
     Event* events = nullptr;
     int ev_cap = 0;
+    unsigned char* d_img = nullptr;   // raster target, grown on demand
+    size_t d_img_bytes = 0;
     // host mirrors / staging
     void* h_stage = nullptr;    // pinned, max(cap*rec, cap*2*real ...)
     size_t h_stage_bytes = 0;
@@ -316,7 +318,7 @@ void free_all(nbody_ctx* c) {
     hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
     if (c->gather && c->gather != c->slot) hipFree(c->gather);
     hipFree(c->slot);
-    hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->counters); hipFree(c->events);
+    hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_meta) hipHostFree(c->h_meta);
     if (c->h_meta_async) hipHostFree(c->h_meta_async);
@@ -463,7 +465,7 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
         HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<float>), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
     }
-    c->h_meta->n = n; c->h_meta->lo = lo; c->h_meta->cnt = cnt; c->h_meta->step = 0;
+    c->h_meta->n = n; c->h_meta->lo = lo; c->h_meta->cnt = cnt; c->h_meta->step = 0; c->h_meta->n_prev = n;
     *c->h_meta_async = *c->h_meta;
     HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
@@ -668,6 +670,32 @@ int nbody_download(nbody_ctx* c, void* block, int* n_out) {
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     *n_out = n;
+    return NBODY_OK;
+}
+
+int nbody_render_image(nbody_ctx* c, unsigned char* img, int width, int height) {
+    if (!c || !img || width <= 0 || height <= 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_render_image: bad argument");
+    if (!c->uploaded) return nbody_fail(NBODY_ERR_STATE, "nbody_render_image before nbody_upload");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    const size_t bytes = (size_t)width * height;
+    if (bytes > c->d_img_bytes) {
+        hipFree(c->d_img);
+        c->d_img = nullptr; c->d_img_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&c->d_img, bytes));
+        c->d_img_bytes = bytes;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_img, 254, bytes, c->stream));                 // src/nbody.cu:534
+    const int literal = c->desc.semantics == NBODY_LITERAL;
+    const int grid = (c->n_upper + 255) / 256 > 0 ? (c->n_upper + 255) / 256 : 1;
+    if (c->desc.precision == NBODY_F64)
+        hipLaunchKernelGGL(render_discs<double>, dim3(grid), dim3(256), 0, c->stream, (const Rec<double>*)c->J,
+                           (const Meta*)c->meta, literal, c->d_img, width, height, c->desc.fieldWidth, c->desc.fieldHeight);
+    else
+        hipLaunchKernelGGL(render_discs<float>, dim3(grid), dim3(256), 0, c->stream, (const Rec<float>*)c->J,
+                           (const Meta*)c->meta, literal, c->d_img, width, height, c->desc.fieldWidth, c->desc.fieldHeight);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(img, c->d_img, bytes, hipMemcpyDeviceToHost, c->stream));   // :537
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return NBODY_OK;
 }
 

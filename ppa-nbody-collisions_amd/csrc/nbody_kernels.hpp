@@ -38,6 +38,8 @@ struct Meta {
     int lo;       // first global index owned by this rank
     int cnt;      // number of bodies owned by this rank
     int step;     // step counter since upload
+    int n_prev;   // body count before the last step's compaction (the reference renders with its block count)
+    int pad[3];
 };
 
 struct Event { int32_t step, i, j, kind; };
@@ -988,6 +990,7 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
     if (g == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         // every block has read meta-independent data only, so the in-place update is race-free
         const int step = meta->step;
+        meta->n_prev = meta->n;
         meta->n = total;
         meta->lo = mine_off;
         meta->cnt = mine_cnt;
@@ -1071,6 +1074,43 @@ __global__ __launch_bounds__(kTile) void ref_layout_move_f32(void* bodyData, con
         M[j] = updM[j];                                                       // :289
         R[j] = updR[j];                                                       // :290
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Image rasteriser: generateImage, src/nbody.cu:294-348, one lane per body, filled discs of value 0 into an
+// image pre-set to 254 (:534); concurrent writers all store 0, so the result is deterministic.  Differences
+// from the reference, both asked for by SURVEY.md 8 f3: the missing `i < numBodies` guard is present, and
+// bodies are read from the {x,y,m,r} records.  `limit` = 128 * (block count of the reference's launch, :535,
+// i.e. the count of the step that produced the state) in literal mode, the body count in clean mode.
+// fp64 contexts rasterise the float-rounded coordinates.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void render_discs(const Rec<T>* __restrict__ J, const Meta* __restrict__ meta,
+                                                    int literal, unsigned char* __restrict__ img, int width,
+                                                    int height, int fieldWidth, int fieldHeight) {
+    const int n = meta->n;
+    long long limit = n;
+    if (literal) {
+        const int np = meta->n_prev;
+        limit = (long long)(np < kTile ? 1 : np / kTile) * kTile;             // :473, :535
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || i >= limit) return;
+    const float px = (float)J[i].x, py = (float)J[i].y;
+    const float r = ((float)J[i].r * width) / fieldWidth;                     // :310
+    const int doubleFieldWidth = fieldWidth << 1, doubleFieldHeight = fieldHeight << 1;   // :314-315
+    const int xc = (int)(((px + fieldWidth) / doubleFieldWidth) * width);     // :318
+    const int yc = (int)(((py + fieldHeight) / doubleFieldHeight) * height);  // :319
+    const int y_min = yc - r < 0 ? 0 : yc - r;                                // :323
+    const int y_max = yc + r >= height ? height : yc + r;                     // :324
+    const int x_min = xc - r < 0 ? 0 : xc - r;                                // :325
+    const int x_max = xc + r > width ? width : xc + r;                        // :326
+    const int r2 = (int)(r * r);
+    for (int y = y_min; y < y_max; ++y)                                       // :328-347
+        for (int x = x_min; x < x_max; ++x) {
+            const int x_sq = (x - xc) * (x - xc), y_sq = (y - yc) * (y - yc);
+            if (x_sq + y_sq <= r2) img[(size_t)width * y + x] = 0;
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -94,3 +94,19 @@ int nbody_state_load(nbody_ctx* ctx, const char* path) {
     if (rc != NBODY_OK) return rc;
     return nbody_ctx_set_steps(ctx, h.steps);
 }
+
+/* saveImageToDisk, src/nbody.cu:350-371 */
+int nbody_write_pgm(const char* path, const unsigned char* img, int width, int height) {
+    if (!path || !img || width <= 0 || height <= 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_write_pgm: bad argument");
+    printf("Saving (%dx%d) to disk\n", width, height);                         /* :356 */
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        fprintf(stderr, "Error writing image to file:%s\nEnsure the the folder exists\n", path);   /* :367-368 */
+        return nbody_fail(NBODY_ERR_IO, "Error writing image to file:%s", path);
+    }
+    fprintf(f, "P5\n%d %d\n255\n", width, height);                             /* :359 */
+    const size_t bytes = (size_t)width * height;
+    const int ok = fwrite(img, 1, bytes, f) == bytes;
+    if (fclose(f) != 0 || !ok) return nbody_fail(NBODY_ERR_IO, "short write to %s", path);
+    return NBODY_OK;
+}

@@ -51,6 +51,9 @@ def port():
         L.oracle_pairs_per_step.restype = ctypes.c_int64
         L.oracle_jlist.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]
         L.oracle_jlist.restype = ctypes.c_int
+        L.oracle_render_f32.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_int]
+        L.oracle_render_f32.restype = None
         L.oracle_set_threads.argtypes = [ctypes.c_int]
         L.oracle_get_max_threads.restype = ctypes.c_int
         _port = L
@@ -69,6 +72,8 @@ def ref():
                                ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
         L.ref_init_bodies.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int] + \
             [ctypes.c_float] * 4
+        L.ref_render.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.ref_rng_ival64.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p]
         L.ref_rng_fval.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_void_p]
@@ -137,6 +142,18 @@ def ref_step(block, n, dt, fw, fh, growth, pre=False):
     preb = np.empty(6 * n, dtype=np.float32) if pre else None
     L.ref_step(block.ctypes.data, ctypes.byref(cn), dt, fw, fh, growth, preb.ctypes.data if pre else None)
     return cn.value, preb
+
+
+def port_render(block, n, blocks, w, h, fw, fh):
+    img = np.zeros(w * h, np.uint8)
+    port().oracle_render_f32(block.ctypes.data, n, blocks, img.ctypes.data, w, h, fw, fh)
+    return img.reshape(h, w)
+
+
+def ref_render(block, n, blocks, w, h, fw, fh):
+    img = np.zeros(w * h, np.uint8)
+    ref().ref_render(block.ctypes.data, n, blocks, img.ctypes.data, w, h, fw, fh)
+    return img.reshape(h, w)
 
 
 def ref_init(n, fw=100000, fh=100000, min_mass=1e4, max_mass=1e17, min_r=50.0, max_r=200.0):

@@ -85,7 +85,10 @@ def test_sharded_protocol_equals_single_rank(world, n0, field, steps):
     import ppa_nbody_collisions_amd as nb
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() * 7 + world * 13 + n0) % 2000
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:     # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, n0, field, steps, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -353,6 +353,55 @@ def test_cli_matches_oracle(nb, tmp_path):
     assert np.array_equal(np.frombuffer(payload, dtype=np.uint32), blk[:6 * n].view(np.uint32))
 
 
+@pytest.mark.parametrize("n,field,w,h", [(1024, 100000, 1024, 1024), (1000, 5000, 320, 200), (300, 2000, 64, 64)])
+def test_render_image_matches_oracle(nb, tmp_path, n, field, w, h):
+    """generateImage + saveImageToDisk: the raster of the state after each step equals the
+    oracle's (which equals the reference's generateImage run through the shim, tests/test_oracle_cpu.py),
+    including the reference's stale block count (bodies past 128*(N_before/128) are not drawn)."""
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field)
+    bodies = nb.init_bodies(cfg)
+    st = nb.Stepper(cfg)
+    st.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    for s in range(3):
+        blocks = 1 if cur < 128 else cur // 128
+        st.step(1)
+        cur, *_ = ol.port_step(blk, cur, DT, field, field, GROWTH, want_events=False)
+        assert np.array_equal(st.render_image(w, h), ol.port_render(blk, cur, blocks, w, h, field, field)), s
+    path = str(tmp_path / "iteration_0.ppm")
+    img = st.render_image(w, h)
+    nb.saveImageToDisk(path, img)
+    raw = open(path, "rb").read()
+    head = b"P5\n%d %d\n255\n" % (w, h)
+    assert raw.startswith(head) and raw[len(head):] == img.tobytes()
+    st.close()
+
+
+def test_cli_images(nb, tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ppa-nbody-collisions_amd", "nbody")
+    cfg = nb.stock_config(particleCount=640, totalIterations=7, save_Image_Every_Xth_Iteration=3, imgWidth=96,
+                          imgHeight=80, fieldWidth=4000, fieldHeight=4000)
+    nb.write_config(str(tmp_path / "nbodyConfig.txt"), cfg)
+    r = subprocess.run([exe, "--images"], cwd=str(tmp_path), capture_output=True, timeout=120)
+    assert r.returncode == 1 and b"Ensure the the folder exists" in r.stderr      # reference: exit(1), :365-370
+    os.mkdir(str(tmp_path / "iter_img"))
+    r = subprocess.run([exe, "--images"], cwd=str(tmp_path), capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert sorted(os.listdir(str(tmp_path / "iter_img"))) == ["iteration_0.ppm", "iteration_3.ppm"]   # 6 is last
+    blk = nb.init_bodies(cfg).contiguousData.copy()
+    cur = 640
+    for k in range(4):
+        blocks = 1 if cur < 128 else cur // 128
+        cur, *_ = ol.port_step(blk, cur, DT, 4000, 4000, GROWTH, want_events=False)
+        if k in (0, 3):
+            raw = open(str(tmp_path / "iter_img" / ("iteration_%d.ppm" % k)), "rb").read()
+            want = ol.port_render(blk, cur, blocks, 96, 80, 4000, 4000)
+            assert raw == b"P5\n96 80\n255\n" + want.tobytes(), k
+
+
 def test_fp64_matches_oracle(nb):
     """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); the HIP path is
     checked bit-exactly against the fp64 instantiation of the oracle."""

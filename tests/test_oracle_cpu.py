@@ -135,3 +135,17 @@ def test_f64_step_consistency():
     assert n32 == n64
     p32, p64 = b32[:2 * n32], b64[:2 * n64]
     assert np.max(np.abs(p32 - p64)) / np.max(np.abs(p64)) < 1e-6
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("n,field,w,h", [(1024, 100000, 1024, 1024), (1000, 5000, 256, 200), (300, 2000, 64, 48),
+                                         (100, 1500, 33, 77)])
+def test_port_render_matches_reference_generateImage(n, field, w, h):
+    """oracle_render_f32 against the reference's own generateImage (src/nbody.cu:294-348) through the shim."""
+    b = ol.ref_init(n, field, field)
+    cur = n
+    for s in range(4):
+        blocks = 1 if cur < 128 else cur // 128
+        cur, _ = ol.ref_step(b, cur, np.float32(0.2), field, field, np.float32(0.1))
+        assert np.array_equal(ol.ref_render(b, cur, blocks, w, h, field, field),
+                              ol.port_render(b, cur, blocks, w, h, field, field)), (n, s)
