@@ -169,8 +169,8 @@ int read_meta(nbody_ctx* c) {
     return NBODY_OK;
 }
 
-// kernel_variant: 0 default | 1 v1 (one body per lane, compiler IEEE sqrt/div) | 2,3,4 v2 with M = 1,2,4 |
-//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 22,24,28 producer/consumer with P = 2,4,8
+// kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
+//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 22,24,25,28 producer/consumer
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -182,13 +182,6 @@ template <>
 void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblocks, bool log) {
     if (log) hipLaunchKernelGGL((forces_v1<double, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
     else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
-}
-
-template <int M>
-void launch_v2(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
-    const int grid = (nblocks + M - 1) / M;
-    if (log) hipLaunchKernelGGL((forces_v2_f32<M, true>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_v2_f32<M, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
 template <int K>
@@ -213,9 +206,6 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
             if (log) hipLaunchKernelGGL((forces_v1<float, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
             else hipLaunchKernelGGL((forces_v1<float, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
             return;
-        case 2: launch_v2<1>(c, p, nblocks, log); return;
-        case 3: launch_v2<2>(c, p, nblocks, log); return;
-        case 4: launch_v2<4>(c, p, nblocks, log); return;
         case 11: launch_v3<1>(c, p, nblocks, log); return;
         case 12: launch_v3<2>(c, p, nblocks, log); return;
         case 14: launch_v3<4>(c, p, nblocks, log); return;
@@ -351,8 +341,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad precision");
     if (d->semantics != NBODY_LITERAL && d->semantics != NBODY_CLEAN)
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad semantics");
-    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 &&
-        ((d->kernel_variant >= 2 && d->kernel_variant <= 4) || d->kernel_variant >= 20))
+    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 && d->kernel_variant >= 20)
         return nbody_fail(NBODY_ERR_INVALID, "kernel_variant %d implements the literal semantics only", d->kernel_variant);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

@@ -274,182 +274,6 @@ __device__ __forceinline__ FastChain fast_chain(float d2) {
     return FastChain{d, __builtin_fmaf(e2, r, r)};
 }
 
-// One pair on the fast path: returns the wave mask of lanes that must be redone by the general code.
-__device__ __forceinline__ unsigned long long fast_pair(float xi, float yi, float ri, const Rec<float>& bj,
-                                                        float& fx, float& fy) {
-    const float dx = bj.x - xi;
-    const float dy = bj.y - yi;
-    const float d2 = (dx * dx) + (dy * dy);
-    const float rs = ri + bj.r;
-    const float q = __builtin_fmaf(rs, rs, kFastLo);     // flag only: contraction is harmless here
-    const unsigned long long flag = __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
-    const FastChain ch = fast_chain(d2);
-    const float mx = bj.m * dx;
-    const float my = bj.m * dy;
-    fx = fx + ch.inv * mx;
-    fy = fy + ch.inv * my;
-    return flag;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "v2" (fp32): 128-lane workgroup, lane t carries the M bodies
-// (b0+m)*128 + t, m < M, of M consecutive reference blocks.  Body m reaches the cyclic tile T as its tile
-// k = T - (b0+m), so all M bodies of a lane read the SAME tile entry (t+off) mod 128 at the same time: one
-// ds_read_b128 and one address computation per M pairs.  Tiles where every body is in the interior of its
-// walk (1 <= k <= nb-2) and the coordinates are bounded go through fast_pair; the first/last tiles of each
-// body, flagged tiles and small N go through the general code.  Accumulation order per body is unchanged.
-// ---------------------------------------------------------------------------------------------------------
-template <int M, bool kLog>
-__global__ __launch_bounds__(kTile) void forces_v2_f32(const Rec<float>* __restrict__ J,
-                                                       const Vec2<float>* __restrict__ Vown,
-                                                       Rec<float>* __restrict__ S_J,
-                                                       Vec2<float>* __restrict__ S_V,
-                                                       const Meta* __restrict__ meta, StepParams<float> p,
-                                                       Event* ev, int ev_cap, Counters* ctr) {
-    typedef float T;
-    __shared__ Rec<T> tile[2][kTile];
-    __shared__ int tile_bad[2][kTile / kWave];             // per staged tile, per wave: unbounded coordinate
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-    const int t = threadIdx.x;
-    const int wave = t / kWave;
-    const int b0 = lo / kTile + blockIdx.x * M;            // first reference block of this workgroup
-    if ((long long)b0 * kTile >= (long long)lo + cnt) return;
-    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool loader = t < N || N >= kTile;               // N < 128: lanes >= N load nothing (:143)
-
-    BodyAcc<T> a[M];
-    Vec2<T> v[M];
-    bool mine[M], active[M];
-    int idx[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const long long i64 = ((long long)b0 + m) * kTile + t;
-        idx[m] = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-        mine[m] = i64 >= lo && i64 < (long long)lo + cnt;
-        active[m] = mine[m] && i64 < N && i64 < (long long)nb * kTile;
-        v[m] = Vec2<T>{0, 0};
-        if (mine[m]) {
-            const Rec<T> me = J[idx[m]];
-            a[m].xi = me.x; a[m].yi = me.y; a[m].mi = me.m; a[m].ri = me.r;
-            v[m] = Vown[idx[m] - lo];
-        } else {
-            a[m].xi = a[m].yi = a[m].mi = a[m].ri = 0;
-        }
-        a[m].fx = 0; a[m].fy = 0; a[m].mnew = a[m].mi; a[m].rnew = a[m].ri; a[m].deleted = 0;
-    }
-    // a lane whose own coordinates are unbounded / non-finite sends its whole wave down the general path
-    bool lane_ok = true;
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-        if (active[m]) lane_ok = lane_ok && (__builtin_fabsf(a[m].xi) < kCoordBound) &&
-                                 (__builtin_fabsf(a[m].yi) < kCoordBound);
-    const bool wave_ok = __ballot(!lane_ok) == 0ull;
-    unsigned long long pairs = 0;
-
-    const long long T_first = b0, T_last = (long long)b0 + (M - 1) + (nb - 1);
-    long long start = (T_first * kTile) % N;               // first body of the current tile (cyclic)
-    auto entry_index = [&](long long st) -> int {
-        long long src = st + t;
-        if (src >= N) src -= N;
-        if (src >= N) src %= N;                            // only when N < 128
-        return (int)src;
-    };
-    auto coord_bad = [](const Rec<T>& r) -> bool {
-        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
-    };
-    {
-        Rec<T> r{0, 0, 0, 0};
-        if (loader) { r = J[entry_index(start)]; tile[0][t] = r; }
-        const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
-        if ((t & (kWave - 1)) == 0) tile_bad[0][wave] = bad;
-    }
-    __syncthreads();
-
-    for (long long Tt = T_first; Tt <= T_last; ++Tt) {
-        const int cur = (int)((Tt - T_first) & 1);
-        const bool have_next = Tt < T_last;
-        long long next_start = start + kTile;
-        while (next_start >= N) next_start -= N;
-        Rec<T> nxt{0, 0, 0, 0};
-        if (have_next && loader) nxt = J[entry_index(next_start)];       // in flight during the tile below
-
-        // general code for body m on this tile (its tile k = Tt - b0 - m), exact for every input
-        auto general = [&](int m, BodyAcc<T>& acc) {
-            const long long k = Tt - b0 - m;
-            if (k < 0 || k >= nb || !active[m]) return;
-            const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;            // :194 (quirk Q1)
-            for (int off = (k == 0 ? 1 : 0); off < L; ++off) {                 // :200-204
-                const int s = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L);   // :207
-                long long j = start + s;
-                if (j >= N) j %= N;
-                interact<T, kLog>(acc, tile[cur][s], p.growth, idx[m], (int)j, ev, ev_cap, ctr, step);
-            }
-        };
-        const long long k_first = Tt - b0 - (M - 1);       // smallest tile index k among the M bodies
-        const long long k_last = Tt - b0;                  // largest
-        const bool interior = k_first >= 1 && k_last <= nb - 2;
-        bool bad_tile = false;
-#pragma unroll
-        for (int w = 0; w < kTile / kWave; ++w) bad_tile = bad_tile || tile_bad[cur][w] != 0;
-        if (interior && wave_ok && !bad_tile) {
-            float fx[M], fy[M];
-#pragma unroll
-            for (int m = 0; m < M; ++m) { fx[m] = a[m].fx; fy[m] = a[m].fy; }
-            unsigned long long flag = 0;
-#pragma unroll 4
-            for (int off = 0; off < kTile; ++off) {
-                const Rec<T> bj = tile[cur][(t + off) & (kTile - 1)];
-#pragma unroll
-                for (int m = 0; m < M; ++m) flag |= fast_pair(a[m].xi, a[m].yi, a[m].ri, bj, fx[m], fy[m]);
-            }
-            if (flag == 0ull) {
-#pragma unroll
-                for (int m = 0; m < M; ++m) { a[m].fx = fx[m]; a[m].fy = fy[m]; }
-            } else {          // some lane of this wave met a collision / tiny distance: redo the tile exactly
-#pragma unroll
-                for (int m = 0; m < M; ++m) general(m, a[m]);
-            }
-        } else {
-#pragma unroll
-            for (int m = 0; m < M; ++m) general(m, a[m]);
-        }
-        // pair accounting (identical for both paths)
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const long long k = Tt - b0 - m;
-            if (k >= 0 && k < nb && active[m]) {
-                const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;
-                pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
-            }
-        }
-        if (have_next) {
-            if (loader) tile[cur ^ 1][t] = nxt;
-            const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
-            if ((t & (kWave - 1)) == 0) tile_bad[cur ^ 1][wave] = bad;
-        }
-        __syncthreads();
-        start = next_start;
-    }
-
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        if (mine[m]) {
-            const int q = idx[m] - lo;
-            if (active[m]) {
-                Rec<T> out; Vec2<T> vout;
-                finish_body<T>(a[m], v[m], p, out, vout);
-                S_J[q] = out;
-                S_V[q] = vout;
-            } else {
-                S_J[q] = Rec<T>{a[m].xi, a[m].yi, a[m].mi, a[m].ri};
-                S_V[q] = v[m];
-            }
-        }
-    }
-    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
-    if ((t & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Force + collision + drift kernel, variant "v3" (fp32): the production kernel.
 //
@@ -1131,7 +955,7 @@ __global__ __launch_bounds__(256) void selftest_ieee_f32(unsigned long long* mis
         const bool r_ok = (__float_as_uint(r1) == __float_as_uint(r2)) || (r1 != r1 && r2 != r2);
         bad_sqrt += !s_ok;
         bad_rcp += !r_ok;
-        // the fast chain of the v2 kernel against the general code, on its whole guarded domain
+        // the fast chain of the fp32 force kernels against the general code, on its whole guarded domain
         if (x >= kFastLo && x <= kFastHi) {
             const FastChain f = fast_chain(x);
             const float c = (s1 * s1) * s1;
