@@ -478,6 +478,19 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
         if (world > 1 && !(c->desc.flags & NBODY_FLAG_GROUP_EXCHANGE))
             return nbody_fail(NBODY_ERR_STATE, "nbody_group_step: context %d lacks NBODY_FLAG_GROUP_EXCHANGE", g);
     }
+    // direct xGMI copies between the ranks' devices (ignored where already enabled / same device)
+    for (int g = 0; g < world; ++g)
+        for (int h = 0; h < world; ++h)
+            if (ctxs[g]->desc.device != ctxs[h]->desc.device) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, ctxs[g]->desc.device, ctxs[h]->desc.device) == hipSuccess && can) {
+                    HIP_TRY(hipSetDevice(ctxs[g]->desc.device));
+                    hipError_t pe = hipDeviceEnablePeerAccess(ctxs[h]->desc.device, 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                        return nbody_fail(NBODY_ERR_HIP, "hipDeviceEnablePeerAccess failed: %s", hipGetErrorString(pe));
+                    (void)hipGetLastError();
+                }
+            }
     std::vector<hipEvent_t> ready(world), done(world);
     for (int g = 0; g < world; ++g) {
         HIP_TRY(hipSetDevice(ctxs[g]->desc.device));

@@ -14,6 +14,7 @@ Outputs (all data: inputs + expected outputs, no reference text):
     config_cases.json       config texts (written by us) with the values/echo/exit status the reference gives
     steps_<case>.npz        initial block, per-step survivor counts, selected post-step blocks (raw fp32 bits)
     big_n65536.json         sha256 + sampled bodies of one literal step at N=65536 (stock radii and radii 0)
+    render_n300.npz         images the reference's generateImage produces for a small dense case
 """
 import ctypes
 import hashlib
@@ -176,6 +177,20 @@ def big_cases():
     json.dump(out, open(os.path.join(HERE, "big_n65536.json"), "w"), indent=1)
 
 
+def render_cases():
+    """generateImage (src/nbody.cu:294-348) of the dense N=300 state after each of 3 steps, 64x48 pixels."""
+    n, field, w, h = 300, 2000, 64, 48
+    b = ol.ref_init(n, field, field)
+    out = {"init": b.view(np.uint32).copy(), "params": np.array([n, field, w, h], dtype=np.int64)}
+    cur = n
+    for s in range(1, 4):
+        blocks = 1 if cur < 128 else cur // 128
+        cur, _ = ol.ref_step(b, cur, DT, field, field, GROWTH)
+        out["img_%d" % s] = ol.ref_render(b, cur, blocks, w, h, field, field)
+        out["n_%d" % s] = np.int32(cur)
+    np.savez_compressed(os.path.join(HERE, "render_n300.npz"), **out)
+
+
 if __name__ == "__main__":
     assert ol.have_ref(), "build oracle/_ref first: make -C oracle ref"
     rng_kat()
@@ -183,3 +198,4 @@ if __name__ == "__main__":
     config_cases()
     step_cases()
     big_cases()
+    render_cases()

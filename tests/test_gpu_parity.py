@@ -378,6 +378,18 @@ def test_render_image_matches_oracle(nb, tmp_path, n, field, w, h):
     st.close()
 
 
+def test_render_image_matches_golden(nb):
+    """The committed images come from the reference's own generateImage (tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(GOLD, "render_n300.npz"))
+    n, field, w, h = [int(x) for x in z["params"]]
+    st = _stepper(nb, n, field, field)
+    st.upload(nb.BodiesData.from_block(z["init"].view(np.float32), n))
+    for s in range(1, 4):
+        st.step(1)
+        assert np.array_equal(st.render_image(w, h), z["img_%d" % s]), s
+    st.close()
+
+
 def test_cli_images(nb, tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -149,3 +149,15 @@ def test_port_render_matches_reference_generateImage(n, field, w, h):
         cur, _ = ol.ref_step(b, cur, np.float32(0.2), field, field, np.float32(0.1))
         assert np.array_equal(ol.ref_render(b, cur, blocks, w, h, field, field),
                               ol.port_render(b, cur, blocks, w, h, field, field)), (n, s)
+
+
+def test_port_render_matches_golden_images():
+    z = np.load(os.path.join(GOLD, "render_n300.npz"))
+    n, field, w, h = [int(x) for x in z["params"]]
+    b = z["init"].view(np.float32).copy()
+    cur = n
+    for s in range(1, 4):
+        blocks = 1 if cur < 128 else cur // 128
+        cur, *_ = ol.port_step(b, cur, np.float32(0.2), field, field, np.float32(0.1), want_events=False)
+        assert cur == int(z["n_%d" % s])
+        assert np.array_equal(ol.port_render(b, cur, blocks, w, h, field, field), z["img_%d" % s])
