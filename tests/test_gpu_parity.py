@@ -180,6 +180,57 @@ def test_sharded_group_equals_single(nb, world):
     grp.close()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_big_golden_n65536_sharded(nb, world):
+    """The N=65536 stock-radii golden (10 095 deletions in one step) through a `world`-rank partition with the
+    AUTOMATIC kernel choice: 8 ranks own 8192 bodies each, which selects the producer/consumer kernel."""
+    g = json.load(open(os.path.join(GOLD, "big_n65536.json")))["stock_radii"]
+    cfg = nb.stock_config(particleCount=65536)
+    grp = nb.StepperGroup(world, cfg=cfg)
+    grp.upload(nb.init_bodies(cfg))
+    grp.step(1)
+    out = grp.download()
+    assert out.numBodies == g["n1"]
+    assert hashlib.sha256(out.block.tobytes()).hexdigest() == g["sha256_post"]
+    grp.step(2)                      # ragged ranges now; compare with the single-rank run
+    one = nb.Stepper(cfg)
+    one.upload(nb.init_bodies(cfg))
+    one.step(3)
+    a, b = grp.download(), one.download()
+    assert a.numBodies == b.numBodies and np.array_equal(bits(a.block), bits(b.block))
+    grp.close(); one.close()
+
+
+def test_ragged_large_n_sampled(nb):
+    """N = 100 003 (not a multiple of 128: frozen tail, truncated last tile, wrapped cyclic tiles), 2 steps,
+    oracle on samples of bodies including the last active block and the frozen tail."""
+    n = 100003
+    cfg = nb.stock_config(particleCount=n, minRadius=5.0, maxRadius=20.0)
+    bodies = nb.init_bodies(cfg)
+    st = nb.Stepper(cfg)
+    st.upload(bodies)
+    st.step(1)
+    out = st.download()
+    assert out.numBodies <= n
+    blk = bodies.contiguousData
+    n_active = (n // 128) * 128
+    for lo in (0, 4093, n_active - 20, n - 12):
+        hi = min(lo + 24, n)
+        P, V, M, R, dl, _ = ol.port_range(blk, n, lo, hi, DT, 100000, 100000, GROWTH)
+        keep = M != 0
+        if out.numBodies == n:       # no deletion anywhere: indices unchanged
+            assert np.array_equal(bits(out.Positions[lo:hi]), bits(P))
+            assert np.array_equal(bits(out.Velocities[lo:hi]), bits(V))
+            assert np.array_equal(bits(out.Masses[lo:hi]), bits(M))
+        assert keep.all() or out.numBodies < n
+    # the whole state against the full oracle step (about 1e10 pairs on the host cores)
+    ref = blk.copy()
+    n1, *_ = ol.port_step(ref, n, DT, 100000, 100000, GROWTH, want_events=False)
+    assert_bodies_equal(out, ref, n1, "N=100003 step 1")
+    assert st.stats().pairs == ol.port().oracle_pairs_per_step(n, ol.LITERAL)
+    st.close()
+
+
 def test_rccl_path_single_rank(nb):
     """The multi-rank code path on one GPU: RCCL loaded by dlopen, a 1-rank communicator from a unique id, the
     per-step slot all-gather and the all-gather based download.  (N>1 ranks cannot run on a 1-GPU box; the
