@@ -118,7 +118,6 @@ struct nbody_ctx {
     Counters* h_counters = nullptr;
     int n_upper = 0;            // host-side upper bound of the global count (exact after a sync)
     int own_upper = 0;          // upper bound of the own count
-    int lo_known = 0;           // own range start as of the last sync (lower bound drifts down only)
     bool uploaded = false;
     int64_t steps = 0;
     // RCCL
@@ -165,7 +164,6 @@ int read_meta(nbody_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_upper = c->h_meta->n;
     c->own_upper = c->h_meta->cnt;
-    c->lo_known = c->h_meta->lo;
     return NBODY_OK;
 }
 
@@ -459,7 +457,7 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->n_upper = n; c->own_upper = cnt; c->lo_known = lo;
+    c->n_upper = n; c->own_upper = cnt;
     c->uploaded = true;
     c->steps = 0;
     c->force_ms = 0; c->force_launches = 0;

@@ -465,6 +465,53 @@ def test_cli_images(nb, tmp_path):
             assert raw == b"P5\n96 80\n255\n" + want.tobytes(), k
 
 
+def test_error_paths(nb):
+    """Every misuse returns an error code + message; nothing exits, throws across the ABI or corrupts state."""
+    cfg = nb.stock_config(particleCount=256)
+    with pytest.raises(nb.NbodyError) as e:
+        nb.Stepper(cfg, capacity=0)
+    assert e.value.status == -1
+    with pytest.raises(nb.NbodyError) as e:
+        nb.Stepper(cfg, device=99)
+    assert e.value.status == -1
+    with pytest.raises(nb.NbodyError) as e:
+        nb.Stepper(cfg, world=2, rank=2)
+    assert e.value.status == -1
+    with pytest.raises(nb.NbodyError) as e:
+        nb.Stepper(cfg, world=2, rank=0)            # RCCL context without a communicator id
+    assert e.value.status == -1
+    with pytest.raises(nb.NbodyError) as e:
+        nb.Stepper(cfg, semantics=nb.CLEAN, kernel_variant=24)
+    assert e.value.status == -1
+    st = nb.Stepper(cfg, record_events=True, event_capacity=4)
+    with pytest.raises(nb.NbodyError) as e:
+        st.step(1)                                   # step before upload
+    assert e.value.status == -9
+    with pytest.raises(nb.NbodyError) as e:
+        st.download()
+    assert e.value.status == -9
+    with pytest.raises(nb.NbodyError) as e:
+        st.upload(nb.init_bodies(nb.stock_config(particleCount=257)))   # beyond capacity
+    assert e.value.status == -7
+    with pytest.raises(nb.NbodyError) as e:
+        st.upload(nb.init_bodies(cfg, nb.F64)) if False else st.load_state("/nonexistent/state.bin")
+    assert e.value.status == -2
+    # event log overflow: counted, not stored, and reported through `total`
+    dense = nb.stock_config(particleCount=256, fieldWidth=800, fieldHeight=800)
+    st2 = nb.Stepper(dense, record_events=True, event_capacity=4)
+    st2.upload(nb.init_bodies(dense))
+    st2.step(1)
+    buf = np.zeros(64, dtype=nb.EVENT_DTYPE)
+    total = ctypes.c_int64(0)
+    assert nb.lib.nbody_get_events(st2._ctx, buf.ctypes.data, 64, ctypes.byref(total)) == 0
+    assert total.value > 4 and np.count_nonzero(buf["i"] | buf["j"]) <= 4
+    # the context is still usable after all of that
+    st.upload(nb.init_bodies(cfg))
+    st.step(2)
+    assert st.body_count() <= 256
+    st.close(); st2.close()
+
+
 def test_fp64_matches_oracle(nb):
     """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); the HIP path is
     checked bit-exactly against the fp64 instantiation of the oracle."""
