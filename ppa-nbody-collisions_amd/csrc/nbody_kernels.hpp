@@ -514,8 +514,17 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
 // First / last tile of a walk (self skip, truncation) and tiles with unbounded coordinates are done by the
 // chain waves alone.  Results are bit-identical to every other variant.
 // ---------------------------------------------------------------------------------------------------------
+// Two workgroups per CU need 2 * ceil(waves per workgroup / 4) wave slots on the fullest SIMD (the dispatcher
+// starts every workgroup on the same SIMD: measured, a 9-wave workgroup with 86 VGPRs = 5 slots per SIMD is
+// alone on its CU).  The register budget is capped accordingly.
+template <int C, int P> constexpr int pc_waves_per_simd() {
+    const int per_wg = (C * (1 + P) + 3) / 4;
+    return 2 * per_wg < 4 ? 4 : (2 * per_wg > 8 ? 8 : 2 * per_wg);
+}
+
 template <int C, int P, int S, bool kLog>
-__global__ __launch_bounds__(kWave * C * (1 + P)) void forces_pc_f32(const Rec<float>* __restrict__ J,
+__global__ __launch_bounds__(kWave * C * (1 + P))
+__attribute__((amdgpu_waves_per_eu(pc_waves_per_simd<C, P>()))) void forces_pc_f32(const Rec<float>* __restrict__ J,
                                                                     const Vec2<float>* __restrict__ Vown,
                                                                     Rec<float>* __restrict__ S_J,
                                                                     Vec2<float>* __restrict__ S_V,
@@ -524,7 +533,7 @@ __global__ __launch_bounds__(kWave * C * (1 + P)) void forces_pc_f32(const Rec<f
                                                                     Counters* ctr) {
     typedef float T;
     static_assert(C == 1 || C == 2, "chain waves per workgroup");
-    static_assert(S % P == 0 && kTile % S == 0 && (S / P) % 2 == 0, "sub-tile split");
+    static_assert(S % P == 0 && kTile % S == 0 && (S / P) % 2 == 0 && S % 16 == 0, "sub-tile split");
     constexpr int kBodies = kWave * C;                     // bodies per workgroup
     constexpr int kSubBlocks = kTile / kBodies;            // workgroups per reference block
     constexpr int kSubs = kTile / S;                       // sub-tiles per tile
@@ -615,13 +624,19 @@ __global__ __launch_bounds__(kWave * C * (1 + P)) void forces_pc_f32(const Rec<f
         for (int q = 0; q < P; ++q) mask |= flagmask[buf][c * P + q];
         const float fx0 = a.fx, fy0 = a.fy;
         float fx = fx0, fy = fy0;
-#pragma unroll 8
-        for (int o = 0; o < S / 2; ++o) {
-            const Term2 tm = terms[buf][o][kWave * c + l];
-            fx = fx + tm.x0;
-            fy = fy + tm.y0;
-            fx = fx + tm.x1;
-            fy = fy + tm.y1;
+#pragma unroll 1
+        for (int o0 = 0; o0 < S / 2; o0 += 8) {
+            Term2 tm[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) tm[o] = terms[buf][o0 + o][kWave * c + l];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                fx = fx + tm[o].x0;
+                fy = fy + tm[o].y0;
+                fx = fx + tm[o].x1;
+                fy = fy + tm[o].y1;
+            }
         }
         a.fx = fx; a.fy = fy;
         if (mask != 0ull) {
@@ -662,12 +677,18 @@ __global__ __launch_bounds__(kWave * C * (1 + P)) void forces_pc_f32(const Rec<f
                 const int buf = gsub & 1;
                 if (!consumer) {
                     unsigned long long flag = 0;
+                    // all tile reads of the sub-tile share first, pinned: with 2-5 waves per SIMD nothing else
+                    // hides a read that is waited for right after it is issued
+                    Rec<T> rec[kPer];
+#pragma unroll
+                    for (int r = 0; r < kPer; ++r) rec[r] = walk[sub * S + r];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < kPer; r += 2) {
                         Term2 tm;
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const Rec<T> bj = walk[sub * S + r + u];
+                            const Rec<T> bj = rec[r + u];
                             const float dx = bj.x - a.xi;
                             const float dy = bj.y - a.yi;
                             const float d2 = (dx * dx) + (dy * dy);
