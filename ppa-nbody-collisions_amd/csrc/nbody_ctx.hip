@@ -168,7 +168,7 @@ int read_meta(nbody_ctx* c) {
 }
 
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
-//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 22,24,25,28 producer/consumer
+//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 22,24,25,28 producer/consumer | 40 pc8
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -212,17 +212,23 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 24: launch_pc<1, 4, 32>(c, p, nblocks, log); return;
         case 25: launch_pc<2, 4, 32>(c, p, nblocks, log); return;
         case 28: launch_pc<1, 8, 64>(c, p, nblocks, log); return;
+        case 40:
+            if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+            else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+            return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
     // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144, profiles/r01_scaling_probe_*.txt):
-    //   >= 96k bodies : one lane per body                          (4 / 2 waves per SIMD)
-    //   >= 48k        : two lanes per body, DPP chain
-    //   below         : producer/consumer, 4 producer waves per chain wave
-    if (c->own_upper >= 98304) launch_v3<1>(c, p, nblocks, log);
-    else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
-    else if (c->desc.semantics == NBODY_LITERAL) launch_pc<1, 4, 32>(c, p, nblocks, log);
-    else launch_v3<4>(c, p, nblocks, log);                 // the pc kernel walks the literal tile order only
+    //   >= 80k bodies : one lane per body (4 / 2 waves per SIMD)
+    //   below         : 8-wave producer/consumer workgroups per 64 bodies (literal semantics),
+    //                   K lanes per body with a DPP chain (clean semantics)
+    if (c->own_upper >= 81920) launch_v3<1>(c, p, nblocks, log);
+    else if (c->desc.semantics == NBODY_LITERAL) {
+        if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+        else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    } else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
+    else launch_v3<4>(c, p, nblocks, log);
 }
 
 template <typename T>
@@ -339,7 +345,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad precision");
     if (d->semantics != NBODY_LITERAL && d->semantics != NBODY_CLEAN)
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad semantics");
-    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 && d->kernel_variant >= 20)
+    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 && d->kernel_variant >= 20)   /* pc, pc8 */
         return nbody_fail(NBODY_ERR_INVALID, "kernel_variant %d implements the literal semantics only", d->kernel_variant);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

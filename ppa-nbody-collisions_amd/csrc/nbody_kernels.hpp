@@ -748,6 +748,245 @@ __attribute__((amdgpu_waves_per_eu(pc_waves_per_simd<C, P>()))) void forces_pc_f
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Force + collision + drift kernel, variant "pc8" (fp32): the producer / consumer scheme with an 8-wave
+// workgroup per 64 bodies.  What the counters of "pc" showed at the 8-rank shape: 5- and 9-wave workgroups
+// leave 2.1 waves per SIMD resident (every workgroup starts on the same SIMD, so two 9-wave workgroups need 6
+// slots there), and short sub-tiles stall on the barrier.  Here: 8 waves land 2-2-2-2 on the SIMDs, two
+// workgroups per CU give 4 waves per SIMD, a sub-tile is half a tile (64 positions): producer p of 7 evaluates
+// positions [9p, 9p+9), the chain wave evaluates position 63 itself, so all 8 waves carry about the same
+// instruction count (9 pairs ~ 63 chain adds + 1 pair).  One barrier per half tile.
+// ---------------------------------------------------------------------------------------------------------
+template <bool kLog>
+__global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
+                    Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
+                    StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
+    typedef float T;
+    constexpr int kP = 7;                                  // producer waves
+    constexpr int kS = 64;                                 // positions per sub-tile
+    constexpr int kPer = 9;                                // positions per producer per sub-tile (7 * 9 = 63)
+    constexpr int kSubs = kTile / kS;
+    __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
+    // two consecutive positions of a lane share a 16-byte slot: the chain wave reads 32 slots per sub-tile
+    struct alignas(16) Term2 { Vec2<T> p[2]; };
+    __shared__ Term2 terms[2][kS / 2][kWave];
+    __shared__ unsigned long long flagmask[2][8];
+    __shared__ int tile_bad[2][2];
+    __shared__ int wg_bad;
+    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    const int tid = threadIdx.x;
+    const int wave = tid / kWave;
+    const int l = tid % kWave;
+    const bool consumer = wave == 0;
+    const int pw = wave - 1;                               // producer index (valid when !consumer)
+    const int wg = blockIdx.x;
+    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
+    const int t = (wg % 2) * kWave + l;                    // threadIdx.x of this lane's body in the reference
+    const long long blk0 = (long long)b * kTile;
+    if (blk0 + (wg % 2) * kWave >= (long long)lo + cnt) return;
+    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
+    const bool loader = tid < kTile && (tid < N || N >= kTile);
+
+    const long long i64 = blk0 + t;
+    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
+    const bool active = mine && i64 < N && i64 < (long long)nb * kTile;
+    BodyAcc<T> a;
+    Vec2<T> v{0, 0};
+    if (mine) {
+        const Rec<T> me = J[i];
+        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
+        if (consumer) v = Vown[i - lo];
+    } else {
+        a.xi = a.yi = a.mi = a.ri = 0;
+    }
+    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
+    unsigned long long pairs = 0;
+
+    if (consumer) __builtin_amdgcn_s_setprio(3);           // the chain wave carries the serial part
+    if (tid == 0) wg_bad = 0;
+    __syncthreads();
+    {
+        const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
+        if (consumer && __ballot(!lane_ok) != 0ull && l == 0) atomicOr(&wg_bad, 1);
+    }
+    long long start = blk0 % N;                            // first body of the current tile (cyclic)
+    auto entry_index = [&](long long st) -> int {
+        long long src = st + tid;
+        if (src >= N) src -= N;
+        if (src >= N) src %= N;                            // only when N < 128
+        return (int)src;
+    };
+    auto coord_bad = [](const Rec<T>& r) -> bool {
+        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
+    };
+    if (tid < kTile) {
+        Rec<T> r{0, 0, 0, 0};
+        if (loader) { r = J[entry_index(start)]; tile[0][tid] = r; tile[0][tid + kTile] = r; }
+        const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
+        if (l == 0) tile_bad[0][wave] = bad;
+    }
+    __syncthreads();
+    const bool all_ok = wg_bad == 0;
+
+    // the fast evaluation of one walk position
+    auto term = [&](const Rec<T>& bj, unsigned long long& flag, float& tx, float& ty) {
+        const float dx = bj.x - a.xi;
+        const float dy = bj.y - a.yi;
+        const float d2 = (dx * dx) + (dy * dy);
+        const float rs = a.ri + bj.r;
+        const float q = __builtin_fmaf(rs, rs, kFastLo);                       // flag only
+        flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
+        const FastChain ch = fast_chain(d2);
+        tx = ch.inv * (bj.m * dx);
+        ty = ch.inv * (bj.m * dy);
+    };
+    // chain-lane general code on walk positions [o0, o1) of tile kk (buffer kk & 1, first body st)
+    auto general = [&](int kk, long long st, int o0, int o1) {
+        const int L = (kk == nb - 1) ? N % (kTile + 1) : kTile;               // :194 (quirk Q1)
+        const int hi = o1 < L ? o1 : L;
+        for (int off = o0; off < hi; ++off) {
+            if (kk == 0 && off == 0) continue;                                 // :200-204
+            const int s = (L == kTile) ? (t + off) : ((t + off) % L);          // :207 (doubled tile: no wrap)
+            long long j = st + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
+            if (j >= N) j %= N;
+            interact<T, kLog>(a, tile[kk & 1][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+        }
+    };
+    // chain wave: the 63 producer terms of a finished sub-tile in walk order, then its own position 63
+    auto drain = [&](int buf, int kk, long long st, int sub) {
+        unsigned long long mask = 0;
+#pragma unroll
+        for (int q = 0; q < kP; ++q) mask |= flagmask[buf][q];
+        const float fx0 = a.fx, fy0 = a.fy;
+        float fx = fx0, fy = fy0;
+        const Rec<T> own = tile[kk & 1][t + sub * kS + (kS - 1)];
+#pragma unroll 1
+        for (int o0 = 0; o0 < 24; o0 += 8) {               // positions 0..47
+            Term2 tm[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) tm[o] = terms[buf][o0 + o][l];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                fx = fx + tm[o].p[0].x; fy = fy + tm[o].p[0].y;
+                fx = fx + tm[o].p[1].x; fy = fy + tm[o].p[1].y;
+            }
+        }
+        {                                                  // positions 48..62 from LDS, 63 evaluated here
+            Term2 tm[8];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) tm[o] = terms[buf][24 + o][l];
+            unsigned long long own_flag = 0;
+            float tx, ty;
+            term(own, own_flag, tx, ty);
+            if (own_flag != 0ull) mask = ~0ull;
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                fx = fx + tm[o].p[0].x; fy = fy + tm[o].p[0].y;
+                fx = fx + tm[o].p[1].x; fy = fy + tm[o].p[1].y;
+            }
+            fx = fx + tm[7].p[0].x; fy = fy + tm[7].p[0].y;
+            fx = fx + tx;
+            fy = fy + ty;
+        }
+        a.fx = fx; a.fy = fy;
+        if (mask != 0ull) {
+            if (((mask >> l) & 1ull) && active) {
+                a.fx = fx0; a.fy = fy0;
+                general(kk, st, sub * kS, sub * kS + kS);
+            }
+        }
+    };
+
+    bool pending = false;
+    int pend_buf = 0, pend_k = 0, pend_sub = 0;
+    long long pend_start = 0;
+    int gsub = 0;
+    for (int k = 0; k < nb; ++k) {                         // :182, tile k of these bodies = cyclic tile b + k
+        const int cur = k & 1;
+        const bool have_next = k + 1 < nb;
+        long long next_start = start + kTile;
+        while (next_start >= N) next_start -= N;
+        Rec<T> nxt{0, 0, 0, 0};
+        if (have_next && loader) nxt = J[entry_index(next_start)];
+        // the other tile buffer is free from here on: its last readers (the chain wave's work on tile k-1's
+        // final sub-tile) ran before the first barrier of tile k
+        auto stage_next = [&]() {
+            if (have_next && tid < kTile) {
+                if (loader) { tile[cur ^ 1][tid] = nxt; tile[cur ^ 1][tid + kTile] = nxt; }
+                const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
+                if (l == 0) tile_bad[cur ^ 1][wave] = bad;
+            }
+        };
+        const bool bad_tile = (tile_bad[cur][0] | tile_bad[cur][1]) != 0;
+        const bool fast_tile = k >= 1 && k <= nb - 2 && all_ok && !bad_tile;   // workgroup-uniform
+        if (fast_tile) {
+#pragma unroll 1
+            for (int sub = 0; sub < kSubs; ++sub) {
+                const int buf = gsub & 1;
+                if (!consumer) {
+                    unsigned long long flag = 0;
+                    const Rec<T>* walk = &tile[cur][t + sub * kS + pw * kPer];
+                    Rec<T> rec[kPer];
+#pragma unroll
+                    for (int r = 0; r < kPer; ++r) rec[r] = walk[r];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < kPer; ++r) {
+                        float tx, ty;
+                        term(rec[r], flag, tx, ty);
+                        terms[buf][(pw * kPer + r) / 2][l].p[(pw * kPer + r) & 1] = Vec2<T>{tx, ty};
+                    }
+                    if (l == 0) flagmask[buf][pw] = flag;
+                } else if (pending) {
+                    drain(pend_buf, pend_k, pend_start, pend_sub);
+                }
+                // the last sub-tile of tile k-1 is drained during sub-tile 0 of tile k, so the buffer of tile k-1
+                // may only be overwritten from sub-tile 1 on
+                if (sub == kSubs - 1) stage_next();
+                __syncthreads();
+                pending = true; pend_buf = buf; pend_k = k; pend_start = start; pend_sub = sub;
+                ++gsub;
+            }
+        } else {
+            if (consumer) {
+                if (pending) drain(pend_buf, pend_k, pend_start, pend_sub);
+                if (active) general(k, start, 0, kTile);
+            }
+            pending = false;
+        }
+        if (consumer && active) {
+            const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;
+            pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+        }
+        if (!fast_tile) {
+            stage_next();
+            __syncthreads();
+        }
+        start = next_start;
+    }
+    if (consumer && pending) drain(pend_buf, pend_k, pend_start, pend_sub);
+
+    if (consumer) {
+        if (mine) {
+            const int q = i - lo;
+            if (active) {
+                Rec<T> out; Vec2<T> vout;
+                finish_body<T>(a, v, p, out, vout);
+                S_J[q] = out;
+                S_V[q] = vout;
+            } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
+                S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
+                S_V[q] = v;
+            }
+        }
+        for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
+        if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Stable compaction of the own range on `mass != 0` (src/nbody.cu:488-510), two small kernels.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCompactBlock = 1024;

@@ -47,7 +47,7 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-VARIANTS = [0, 1, 11, 12, 14, 18, 22, 24, 25, 28]   # automatic | v1 | v3 K=1,2,4,8 | pc (csrc/nbody_ctx.hip)
+VARIANTS = [0, 1, 11, 12, 14, 18, 22, 24, 25, 28, 40]   # automatic | v1 | v3 K=1,2,4,8 | pc (csrc/nbody_ctx.hip)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
