@@ -231,6 +231,26 @@ def test_ragged_large_n_sampled(nb):
     st.close()
 
 
+@pytest.mark.parametrize("precision,n", [(0, 1048576), (1, 131072)])
+def test_max_size_sampled(nb, precision, n):
+    """configs[4] sizes: N = 1 Mi bodies (fp32: one step is 1.1e12 pairs) and a large fp64 case; the oracle on
+    spread samples of bodies, bit-exact."""
+    cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg, precision)
+    st = nb.Stepper(cfg, precision=precision)
+    st.upload(bodies)
+    st.step(1)
+    out = st.download()
+    assert out.numBodies == n
+    dt, gr = (float(DT), float(GROWTH)) if precision else (DT, GROWTH)
+    for lo in (0, 333 * 128 + 77, n - 128 - 5, n - 8):
+        P, V, M, R, dl, _ = ol.port_range(bodies.contiguousData, n, lo, lo + 8, dt, 100000, 100000, gr)
+        assert np.array_equal(bits(out.Positions[lo:lo + 8]), bits(P))
+        assert np.array_equal(bits(out.Velocities[lo:lo + 8]), bits(V))
+    assert st.stats().pairs == ol.port().oracle_pairs_per_step(n, ol.LITERAL)
+    st.close()
+
+
 def test_rccl_path_single_rank(nb):
     """The multi-rank code path on one GPU: RCCL loaded by dlopen, a 1-rank communicator from a unique id, the
     per-step slot all-gather and the all-gather based download.  (N>1 ranks cannot run on a 1-GPU box; the
