@@ -168,7 +168,7 @@ int read_meta(nbody_ctx* c) {
 }
 
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
-//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 22,24,25,28 producer/consumer | 40 pc8
+//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 40 pc8 (producer/consumer)
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -189,12 +189,11 @@ void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-template <int C, int P, int S>
-void launch_pc(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
-    const int grid = nblocks * (kTile / (kWave * C));
-    const int threads = kWave * C * (1 + P);
-    if (log) hipLaunchKernelGGL((forces_pc_f32<C, P, S, true>), dim3(grid), dim3(threads), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_pc_f32<C, P, S, false>), dim3(grid), dim3(threads), 0, c->stream, NB_FORCES_ARGS(float));
+template <bool kUnused = false>
+void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
+    if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
 template <>
@@ -208,14 +207,7 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 12: launch_v3<2>(c, p, nblocks, log); return;
         case 14: launch_v3<4>(c, p, nblocks, log); return;
         case 18: launch_v3<8>(c, p, nblocks, log); return;
-        case 22: launch_pc<1, 2, 16>(c, p, nblocks, log); return;
-        case 24: launch_pc<1, 4, 32>(c, p, nblocks, log); return;
-        case 25: launch_pc<2, 4, 32>(c, p, nblocks, log); return;
-        case 28: launch_pc<1, 8, 64>(c, p, nblocks, log); return;
-        case 40:
-            if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-            else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-            return;
+        case 40: launch_pc8<>(c, p, nblocks, log); return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
@@ -224,10 +216,8 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //   below         : 8-wave producer/consumer workgroups per 64 bodies (literal semantics),
     //                   K lanes per body with a DPP chain (clean semantics)
     if (c->own_upper >= 81920) launch_v3<1>(c, p, nblocks, log);
-    else if (c->desc.semantics == NBODY_LITERAL) {
-        if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-        else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(nblocks * 2), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    } else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
+    else if (c->desc.semantics == NBODY_LITERAL) launch_pc8<>(c, p, nblocks, log);
+    else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
     else launch_v3<4>(c, p, nblocks, log);
 }
 
@@ -345,7 +335,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad precision");
     if (d->semantics != NBODY_LITERAL && d->semantics != NBODY_CLEAN)
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad semantics");
-    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 && d->kernel_variant >= 20)   /* pc, pc8 */
+    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 && d->kernel_variant == 40)   /* pc8 */
         return nbody_fail(NBODY_ERR_INVALID, "kernel_variant %d implements the literal semantics only", d->kernel_variant);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);

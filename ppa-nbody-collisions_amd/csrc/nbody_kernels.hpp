@@ -499,262 +499,27 @@ __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __re
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "pc" (fp32, producer / consumer): for ranks that own far fewer
+// Force + collision + drift kernel, variant "pc8" (fp32, producer / consumer): for ranks that own far fewer
 // bodies than the chip has lanes (strong scaling).
 //
-// The per-body force sum is a strictly ordered chain of N fp32 adds; only the TERMS are independent.  A
-// workgroup therefore has C chain ("consumer") waves - one lane per body, so every chain add instruction does
-// 64 useful adds - and C*P producer waves that evaluate the terms with the fast chain and hand them over
-// through LDS:  producer (c, p) evaluates walk positions [p*S/P, (p+1)*S/P) of every sub-tile of S positions
-// for the 64 bodies of chain wave c and stores the terms at terms[buf][position][body]; one barrier later
-// the chain wave adds the S terms of each body in walk order.  Term hand-over is double buffered, the chain
-// waves run one sub-tile behind the producers, also across tile boundaries.  Producers never touch masses,
-// radii, deletions or events: positions they flag (possible collision / distance below the proved domain) are
-// reported per sub-tile as a 64-bit lane mask and the chain lane redoes that sub-tile with the general code.
-// First / last tile of a walk (self skip, truncation) and tiles with unbounded coordinates are done by the
-// chain waves alone.  Results are bit-identical to every other variant.
-// ---------------------------------------------------------------------------------------------------------
-// Two workgroups per CU need 2 * ceil(waves per workgroup / 4) wave slots on the fullest SIMD (the dispatcher
-// starts every workgroup on the same SIMD: measured, a 9-wave workgroup with 86 VGPRs = 5 slots per SIMD is
-// alone on its CU).  The register budget is capped accordingly.
-template <int C, int P> constexpr int pc_waves_per_simd() {
-    const int per_wg = (C * (1 + P) + 3) / 4;
-    return 2 * per_wg < 4 ? 4 : (2 * per_wg > 8 ? 8 : 2 * per_wg);
-}
-
-template <int C, int P, int S, bool kLog>
-__global__ __launch_bounds__(kWave * C * (1 + P))
-__attribute__((amdgpu_waves_per_eu(pc_waves_per_simd<C, P>()))) void forces_pc_f32(const Rec<float>* __restrict__ J,
-                                                                    const Vec2<float>* __restrict__ Vown,
-                                                                    Rec<float>* __restrict__ S_J,
-                                                                    Vec2<float>* __restrict__ S_V,
-                                                                    const Meta* __restrict__ meta,
-                                                                    StepParams<float> p, Event* ev, int ev_cap,
-                                                                    Counters* ctr) {
-    typedef float T;
-    static_assert(C == 1 || C == 2, "chain waves per workgroup");
-    static_assert(S % P == 0 && kTile % S == 0 && (S / P) % 2 == 0 && S % 16 == 0, "sub-tile split");
-    constexpr int kBodies = kWave * C;                     // bodies per workgroup
-    constexpr int kSubBlocks = kTile / kBodies;            // workgroups per reference block
-    constexpr int kSubs = kTile / S;                       // sub-tiles per tile
-    constexpr int kPer = S / P;                            // walk positions per producer per sub-tile
-    __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
-    // terms of two consecutive walk positions share one 16-byte slot: {tx(o), ty(o), tx(o+1), ty(o+1)}
-    struct alignas(16) Term2 { float x0, y0, x1, y1; };
-    __shared__ Term2 terms[2][S / 2][kBodies];
-    __shared__ unsigned long long flagmask[2][C * P];
-    __shared__ int tile_bad[2][2];
-    __shared__ int wg_bad;
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-    const int tid = threadIdx.x;
-    const int wave = tid / kWave;
-    const int l = tid % kWave;
-    const bool consumer = wave < C;
-    const int pw = wave - C;                               // producer wave index (valid when !consumer)
-    const int c = consumer ? wave : pw / P;                // chain wave this wave works for
-    const int pslice = consumer ? 0 : pw % P;
-    const int wg = blockIdx.x;
-    const int b = lo / kTile + wg / kSubBlocks;            // reference block
-    const int t0 = (wg % kSubBlocks) * kBodies;
-    const int t = t0 + kWave * c + l;                      // threadIdx.x of this lane's body in the reference
-    const long long blk0 = (long long)b * kTile;
-    if (blk0 + t0 >= (long long)lo + cnt) return;
-    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool loader = tid < kTile && (tid < N || N >= kTile);
-
-    const long long i64 = blk0 + t;
-    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && i64 < (long long)nb * kTile;
-    BodyAcc<T> a;
-    Vec2<T> v{0, 0};
-    if (mine) {
-        const Rec<T> me = J[i];
-        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
-        if (consumer) v = Vown[i - lo];
-    } else {
-        a.xi = a.yi = a.mi = a.ri = 0;
-    }
-    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
-    unsigned long long pairs = 0;
-
-    // the chain waves carry the serial part: let them issue first
-    if (consumer) __builtin_amdgcn_s_setprio(3);
-    if (tid == 0) wg_bad = 0;
-    __syncthreads();
-    {
-        const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
-        if (consumer && __ballot(!lane_ok) != 0ull && l == 0) atomicOr(&wg_bad, 1);
-    }
-    long long start = blk0 % N;                            // first body of the current tile (cyclic)
-    auto entry_index = [&](long long st) -> int {
-        long long src = st + tid;
-        if (src >= N) src -= N;
-        if (src >= N) src %= N;                            // only when N < 128
-        return (int)src;
-    };
-    auto coord_bad = [](const Rec<T>& r) -> bool {
-        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
-    };
-    if (tid < kTile) {
-        Rec<T> r{0, 0, 0, 0};
-        if (loader) { r = J[entry_index(start)]; tile[0][tid] = r; tile[0][tid + kTile] = r; }
-        const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
-        if (l == 0) tile_bad[0][wave] = bad;
-    }
-    __syncthreads();
-    const bool all_ok = wg_bad == 0;
-
-    // chain-lane general code on walk positions [o0, o1) of tile kk (buffer kk & 1, first body st)
-    auto general = [&](int kk, long long st, int o0, int o1) {
-        const int L = (kk == nb - 1) ? N % (kTile + 1) : kTile;               // :194 (quirk Q1)
-        const int hi = o1 < L ? o1 : L;
-        for (int off = o0; off < hi; ++off) {
-            if (kk == 0 && off == 0) continue;                                 // :200-204
-            const int s = (L == kTile) ? (t + off) : ((t + off) % L);          // :207 (doubled tile: no wrap)
-            long long j = st + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
-            if (j >= N) j %= N;
-            interact<T, kLog>(a, tile[kk & 1][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-        }
-    };
-    // chain wave: add the S terms of a finished sub-tile in walk order; redo flagged lanes exactly
-    auto drain = [&](int buf, int kk, long long st, int sub) {
-        unsigned long long mask = 0;
-#pragma unroll
-        for (int q = 0; q < P; ++q) mask |= flagmask[buf][c * P + q];
-        const float fx0 = a.fx, fy0 = a.fy;
-        float fx = fx0, fy = fy0;
-#pragma unroll 1
-        for (int o0 = 0; o0 < S / 2; o0 += 8) {
-            Term2 tm[8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) tm[o] = terms[buf][o0 + o][kWave * c + l];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                fx = fx + tm[o].x0;
-                fy = fy + tm[o].y0;
-                fx = fx + tm[o].x1;
-                fy = fy + tm[o].y1;
-            }
-        }
-        a.fx = fx; a.fy = fy;
-        if (mask != 0ull) {
-            if (((mask >> l) & 1ull) && active) {
-                a.fx = fx0; a.fy = fy0;
-                general(kk, st, sub * S, sub * S + S);
-            }
-        }
-    };
-
-    bool pending = false;
-    int pend_buf = 0, pend_k = 0, pend_sub = 0;
-    long long pend_start = 0;
-    int gsub = 0;
-    for (int k = 0; k < nb; ++k) {                         // :182, tile k of these bodies = cyclic tile b + k
-        const int cur = k & 1;
-        const bool have_next = k + 1 < nb;
-        long long next_start = start + kTile;
-        while (next_start >= N) next_start -= N;
-        Rec<T> nxt{0, 0, 0, 0};
-        if (have_next && loader) nxt = J[entry_index(next_start)];
-
-        // the other tile buffer is free from here on: its last readers (the chain waves' redo of tile k-1's
-        // final sub-tile) ran before the first barrier of tile k
-        auto stage_next = [&]() {
-            if (have_next && tid < kTile) {
-                if (loader) { tile[cur ^ 1][tid] = nxt; tile[cur ^ 1][tid + kTile] = nxt; }
-                const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
-                if (l == 0) tile_bad[cur ^ 1][wave] = bad;
-            }
-        };
-        const bool bad_tile = (tile_bad[cur][0] | tile_bad[cur][1]) != 0;
-        const bool fast_tile = k >= 1 && k <= nb - 2 && all_ok && !bad_tile;   // workgroup-uniform
-        if (fast_tile) {
-            const Rec<T>* walk = &tile[cur][t + pslice * kPer];
-#pragma unroll 1
-            for (int sub = 0; sub < kSubs; ++sub) {
-                const int buf = gsub & 1;
-                if (!consumer) {
-                    unsigned long long flag = 0;
-                    // all tile reads of the sub-tile share first, pinned: with 2-5 waves per SIMD nothing else
-                    // hides a read that is waited for right after it is issued
-                    Rec<T> rec[kPer];
-#pragma unroll
-                    for (int r = 0; r < kPer; ++r) rec[r] = walk[sub * S + r];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r < kPer; r += 2) {
-                        Term2 tm;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const Rec<T> bj = rec[r + u];
-                            const float dx = bj.x - a.xi;
-                            const float dy = bj.y - a.yi;
-                            const float d2 = (dx * dx) + (dy * dy);
-                            const float rs = a.ri + bj.r;
-                            const float q = __builtin_fmaf(rs, rs, kFastLo);   // flag only
-                            flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
-                            const FastChain ch = fast_chain(d2);
-                            const float tx = ch.inv * (bj.m * dx), ty = ch.inv * (bj.m * dy);
-                            if (u == 0) { tm.x0 = tx; tm.y0 = ty; } else { tm.x1 = tx; tm.y1 = ty; }
-                        }
-                        terms[buf][(pslice * kPer + r) / 2][kWave * c + l] = tm;
-                    }
-                    if (l == 0) flagmask[buf][pw] = flag;
-                } else if (pending) {
-                    drain(pend_buf, pend_k, pend_start, pend_sub);
-                }
-                if (sub == kSubs - 1) stage_next();        // published by this sub-tile's barrier
-                __syncthreads();
-                pending = true; pend_buf = buf; pend_k = k; pend_start = start; pend_sub = sub;
-                ++gsub;
-            }
-        } else {
-            if (consumer) {
-                if (pending) drain(pend_buf, pend_k, pend_start, pend_sub);
-                if (active) general(k, start, 0, kTile);
-            }
-            pending = false;
-        }
-        if (consumer && active) {
-            const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;
-            pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
-        }
-        if (!fast_tile) {
-            stage_next();
-            __syncthreads();
-        }
-        start = next_start;
-    }
-    if (consumer && pending) drain(pend_buf, pend_k, pend_start, pend_sub);
-
-    if (consumer) {
-        if (mine) {
-            const int q = i - lo;
-            if (active) {
-                Rec<T> out; Vec2<T> vout;
-                finish_body<T>(a, v, p, out, vout);
-                S_J[q] = out;
-                S_V[q] = vout;
-            } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
-                S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
-                S_V[q] = v;
-            }
-        }
-        for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
-        if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "pc8" (fp32): the producer / consumer scheme with an 8-wave
-// workgroup per 64 bodies.  What the counters of "pc" showed at the 8-rank shape: 5- and 9-wave workgroups
-// leave 2.1 waves per SIMD resident (every workgroup starts on the same SIMD, so two 9-wave workgroups need 6
-// slots there), and short sub-tiles stall on the barrier.  Here: 8 waves land 2-2-2-2 on the SIMDs, two
-// workgroups per CU give 4 waves per SIMD, a sub-tile is half a tile (64 positions): producer p of 7 evaluates
-// positions [9p, 9p+9), the chain wave evaluates position 63 itself, so all 8 waves carry about the same
-// instruction count (9 pairs ~ 63 chain adds + 1 pair).  One barrier per half tile.
+// The per-body force sum is a strictly ordered chain of N fp32 adds; only the TERMS are independent, and a wave
+// cannot issue more than one VALU per ~5 cycles, so with N/G bodies per GPU there are too few chains to keep
+// the SIMDs busy.  A workgroup of 8 waves serves 64 bodies: wave 0 is the chain wave (one lane per body, so
+// every chain add instruction does 64 useful adds), waves 1..7 are producers.  A sub-tile is half a tile (64
+// walk positions): producer p evaluates positions [9p, 9p+9) with the fast chain and stores the terms in LDS
+// (two consecutive positions of a lane share a 16-byte slot), the chain wave evaluates position 63 itself, so
+// all 8 waves carry about the same instruction count (9 pairs ~ 63 chain adds + 1 pair).  One barrier per
+// sub-tile; term hand-over is double buffered and the chain wave runs one sub-tile behind the producers, also
+// across tile boundaries.  Producers never touch masses, radii, deletions or events: positions they flag
+// (possible collision / distance below the proved domain) are reported per sub-tile as a 64-bit lane mask and
+// the chain lane redoes that sub-tile with the general code.  First / last tile of a walk (self skip,
+// truncation) and tiles with unbounded coordinates are done by the chain wave alone.
+//
+// Geometry from measurement (profiles/): the dispatcher starts every workgroup on the same SIMD, so two 9-wave
+// workgroups need 6 wave slots there and 5-wave workgroups leave 2.1 waves per SIMD resident; 8 waves land
+// 2-2-2-2 and two workgroups per CU give 4 waves per SIMD.  Short sub-tiles stall on the barrier; reads of
+// tile records and terms are issued in batches ahead of their use (nothing else hides LDS latency at this
+// occupancy).  Results are bit-identical to every other variant.
 // ---------------------------------------------------------------------------------------------------------
 template <bool kLog>
 __global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))

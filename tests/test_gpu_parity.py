@@ -47,7 +47,7 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-VARIANTS = [0, 1, 11, 12, 14, 18, 22, 24, 25, 28, 40]   # automatic | v1 | v3 K=1,2,4,8 | pc (csrc/nbody_ctx.hip)
+VARIANTS = [0, 1, 11, 12, 14, 18, 40]   # automatic | v1 | v3 K=1,2,4,8 | pc8 (csrc/nbody_ctx.hip)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -501,7 +501,7 @@ def test_error_paths(nb):
         nb.Stepper(cfg, world=2, rank=0)            # RCCL context without a communicator id
     assert e.value.status == -1
     with pytest.raises(nb.NbodyError) as e:
-        nb.Stepper(cfg, semantics=nb.CLEAN, kernel_variant=24)
+        nb.Stepper(cfg, semantics=nb.CLEAN, kernel_variant=40)
     assert e.value.status == -1
     st = nb.Stepper(cfg, record_events=True, event_capacity=4)
     with pytest.raises(nb.NbodyError) as e:
