@@ -19,6 +19,11 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def pytest_configure(config):
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, like __graft_entry__.build()
+    lib = os.path.join(ROOT, "ppa-nbody-collisions_amd", "libnbody_mi355x.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "ppa-nbody-collisions_amd", "csrc"), "all"])
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref/libnbody_ref.so (built where /root/reference exists)")
 
