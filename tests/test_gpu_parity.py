@@ -201,6 +201,24 @@ def test_big_golden_n65536_sharded(nb, world):
     grp.close(); one.close()
 
 
+def test_headline_size_eight_ranks_equals_one(nb):
+    """BASELINE.json metric shape: N=262144 range-partitioned over 8 ranks (automatic kernel choice = the
+    producer/consumer kernel on 32768 own bodies) against the single-rank run, whole state, bit for bit."""
+    cfg = nb.stock_config(particleCount=262144, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg)
+    grp = nb.StepperGroup(8, cfg=cfg)
+    grp.upload(bodies)
+    grp.step(2)
+    one = nb.Stepper(cfg)
+    one.upload(bodies)
+    one.step(2)
+    a, b = grp.download(), one.download()
+    assert a.numBodies == b.numBodies
+    assert np.array_equal(bits(a.block), bits(b.block))
+    assert sum(r.stats().pairs for r in grp.ranks) == one.stats().pairs
+    grp.close(); one.close()
+
+
 def test_ragged_large_n_sampled(nb):
     """N = 100 003 (not a multiple of 128: frozen tail, truncated last tile, wrapped cyclic tiles), 2 steps,
     oracle on samples of bodies including the last active block and the frozen tail."""
