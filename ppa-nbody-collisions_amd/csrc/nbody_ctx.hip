@@ -213,8 +213,7 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
     // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144, profiles/r01_scaling_probe_*.txt):
     //   >= 80k bodies : one lane per body (4 / 2 waves per SIMD)
-    //   below         : 8-wave producer/consumer workgroups per 64 bodies (literal semantics),
-    //                   K lanes per body with a DPP chain (clean semantics)
+    //   below         : 8-wave producer/consumer workgroups per 64 bodies
     if (c->own_upper >= 81920) launch_v3<1>(c, p, nblocks, log);
     else if (c->desc.semantics == NBODY_LITERAL) launch_pc8<>(c, p, nblocks, log);
     else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
@@ -335,8 +334,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad precision");
     if (d->semantics != NBODY_LITERAL && d->semantics != NBODY_CLEAN)
         return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: bad semantics");
-    if (d->semantics == NBODY_CLEAN && d->precision == NBODY_F32 && d->kernel_variant == 40)   /* pc8 */
-        return nbody_fail(NBODY_ERR_INVALID, "kernel_variant %d implements the literal semantics only", d->kernel_variant);
+
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)

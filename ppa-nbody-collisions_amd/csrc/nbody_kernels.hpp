@@ -550,12 +550,14 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
     const long long blk0 = (long long)b * kTile;
     if (blk0 + (wg % 2) * kWave >= (long long)lo + cnt) return;
     const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool loader = tid < kTile && (tid < N || N >= kTile);
+    const bool lit = p.literal != 0;                       // else NBODY_CLEAN: see forces_v3_f32
+    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
+    const int wbase = lit ? t : 0;                         // tile entry of walk position 0 for this lane
 
     const long long i64 = blk0 + t;
     const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
     const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && i64 < (long long)nb * kTile;
+    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
     BodyAcc<T> a;
     Vec2<T> v{0, 0};
     if (mine) {
@@ -575,20 +577,29 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
         const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
         if (consumer && __ballot(!lane_ok) != 0ull && l == 0) atomicOr(&wg_bad, 1);
     }
-    long long start = blk0 % N;                            // first body of the current tile (cyclic)
+    long long start = lit ? blk0 % N : 0;                  // first body of the current tile
+    // this thread's entry of the tile starting at body st, or -1 if it has none
     auto entry_index = [&](long long st) -> int {
+        if (tid >= kTile) return -1;
         long long src = st + tid;
+        if (!lit) return src < N ? (int)src : -1;
+        if (N < kTile && tid >= N) return -1;              // lanes >= N load nothing (:143)
         if (src >= N) src -= N;
         if (src >= N) src %= N;                            // only when N < 128
         return (int)src;
+    };
+    auto tile_len = [&](int kk, long long st) -> int {
+        if (lit) return (kk == nb - 1) ? N % (kTile + 1) : kTile;             // :194 (quirk Q1)
+        return (N - st) < kTile ? (int)(N - st) : kTile;
     };
     auto coord_bad = [](const Rec<T>& r) -> bool {
         return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
     };
     if (tid < kTile) {
         Rec<T> r{0, 0, 0, 0};
-        if (loader) { r = J[entry_index(start)]; tile[0][tid] = r; tile[0][tid + kTile] = r; }
-        const bool bad = __ballot(loader && coord_bad(r)) != 0ull;
+        const int e = entry_index(start);
+        if (e >= 0) { r = J[e]; tile[0][tid] = r; tile[0][tid + kTile] = r; }
+        const bool bad = __ballot(e >= 0 && coord_bad(r)) != 0ull;
         if (l == 0) tile_bad[0][wave] = bad;
     }
     __syncthreads();
@@ -608,13 +619,21 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
     };
     // chain-lane general code on walk positions [o0, o1) of tile kk (buffer kk & 1, first body st)
     auto general = [&](int kk, long long st, int o0, int o1) {
-        const int L = (kk == nb - 1) ? N % (kTile + 1) : kTile;               // :194 (quirk Q1)
+        const int L = tile_len(kk, st);
         const int hi = o1 < L ? o1 : L;
         for (int off = o0; off < hi; ++off) {
-            if (kk == 0 && off == 0) continue;                                 // :200-204
-            const int s = (L == kTile) ? (t + off) : ((t + off) % L);          // :207 (doubled tile: no wrap)
-            long long j = st + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
-            if (j >= N) j %= N;
+            int s;
+            long long j;
+            if (lit) {
+                if (kk == 0 && off == 0) continue;                             // :200-204
+                s = (L == kTile) ? (t + off) : ((t + off) % L);                // :207 (doubled tile: no wrap)
+                j = st + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
+                if (j >= N) j %= N;
+            } else {
+                s = off;
+                j = st + off;
+                if (j == i64) continue;
+            }
             interact<T, kLog>(a, tile[kk & 1][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
         }
     };
@@ -625,7 +644,7 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
         for (int q = 0; q < kP; ++q) mask |= flagmask[buf][q];
         const float fx0 = a.fx, fy0 = a.fy;
         float fx = fx0, fy = fy0;
-        const Rec<T> own = tile[kk & 1][t + sub * kS + (kS - 1)];
+        const Rec<T> own = tile[kk & 1][wbase + sub * kS + (kS - 1)];
 #pragma unroll 1
         for (int o0 = 0; o0 < 24; o0 += 8) {               // positions 0..47
             Term2 tm[8];
@@ -668,31 +687,35 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
     int pend_buf = 0, pend_k = 0, pend_sub = 0;
     long long pend_start = 0;
     int gsub = 0;
-    for (int k = 0; k < nb; ++k) {                         // :182, tile k of these bodies = cyclic tile b + k
+    for (int k = 0; k < ntiles; ++k) {                     // :182, literal: tile k of these bodies = cyclic tile b + k
         const int cur = k & 1;
-        const bool have_next = k + 1 < nb;
+        const bool have_next = k + 1 < ntiles;
         long long next_start = start + kTile;
-        while (next_start >= N) next_start -= N;
+        if (lit) while (next_start >= N) next_start -= N;
         Rec<T> nxt{0, 0, 0, 0};
-        if (have_next && loader) nxt = J[entry_index(next_start)];
+        const int e_next = have_next ? entry_index(next_start) : -1;
+        if (e_next >= 0) nxt = J[e_next];
         // the other tile buffer is free from here on: its last readers (the chain wave's work on tile k-1's
         // final sub-tile) ran before the first barrier of tile k
         auto stage_next = [&]() {
             if (have_next && tid < kTile) {
-                if (loader) { tile[cur ^ 1][tid] = nxt; tile[cur ^ 1][tid + kTile] = nxt; }
-                const bool bad = __ballot(loader && coord_bad(nxt)) != 0ull;
+                if (e_next >= 0) { tile[cur ^ 1][tid] = nxt; tile[cur ^ 1][tid + kTile] = nxt; }
+                const bool bad = __ballot(e_next >= 0 && coord_bad(nxt)) != 0ull;
                 if (l == 0) tile_bad[cur ^ 1][wave] = bad;
             }
         };
         const bool bad_tile = (tile_bad[cur][0] | tile_bad[cur][1]) != 0;
-        const bool fast_tile = k >= 1 && k <= nb - 2 && all_ok && !bad_tile;   // workgroup-uniform
+        const int Lk = tile_len(k, start);
+        // tiles whose every position is an ordinary pair for every lane of the workgroup (workgroup-uniform)
+        const bool interior = lit ? (k >= 1 && k <= nb - 2) : (Lk == kTile && k != b);
+        const bool fast_tile = interior && all_ok && !bad_tile;
         if (fast_tile) {
 #pragma unroll 1
             for (int sub = 0; sub < kSubs; ++sub) {
                 const int buf = gsub & 1;
                 if (!consumer) {
                     unsigned long long flag = 0;
-                    const Rec<T>* walk = &tile[cur][t + sub * kS + pw * kPer];
+                    const Rec<T>* walk = &tile[cur][wbase + sub * kS + pw * kPer];
                     Rec<T> rec[kPer];
 #pragma unroll
                     for (int r = 0; r < kPer; ++r) rec[r] = walk[r];
@@ -722,10 +745,13 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
             pending = false;
         }
         if (consumer && active) {
-            const int L = (k == nb - 1) ? N % (kTile + 1) : kTile;
-            pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
+            if (lit) pairs += (k == 0) ? (Lk > 0 ? Lk - 1 : 0) : Lk;
+            else pairs += Lk - ((i64 >= start && i64 < start + Lk) ? 1 : 0);
         }
         if (!fast_tile) {
+            // the chain wave may still be reading tile k-1 (its drain of that tile's last sub-tile above): the
+            // buffer stage_next() overwrites.  Everyone waits for it before the staging write.
+            __syncthreads();
             stage_next();
             __syncthreads();
         }

@@ -145,6 +145,32 @@ def test_extreme_values_take_the_general_path(nb, variant):
     st.close()
 
 
+@pytest.mark.parametrize("variant", [0, 11, 40])
+def test_unbounded_tile_mid_walk(nb, variant):
+    """A tile with an out-of-range coordinate in the MIDDLE of every other body's walk (not in their own block):
+    the fast path must hand exactly that tile to the general code and resume, for all kernels (this is the
+    non-fast-tile-between-fast-tiles path of the producer/consumer kernel)."""
+    n = 4096
+    cfg = nb.stock_config(particleCount=n, fieldWidth=30000, fieldHeight=30000)
+    bodies = nb.init_bodies(cfg)
+    bodies.Positions[1500] = [3e12, -7e11]
+    bodies.Positions[2700] = [np.inf, 1.0]
+    st = nb.Stepper(cfg, kernel_variant=variant, record_events=True)
+    st.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    for s in range(3):
+        st.step(1)
+        cur, stats, ab, de, _ = ol.port_step(blk, cur, DT, 30000, 30000, GROWTH)
+        ev = st.events()
+        ev = ev[ev["step"] == s]
+        assert sorted((int(e["i"]), int(e["j"])) for e in ev[ev["kind"] == 0]) == \
+            sorted((int(x), int(y)) for x, y in ab), "E_t step %d" % s
+        out = st.download()
+        assert out.numBodies == cur and _nan_aware_equal(out.block, blk[:6 * cur]), "step %d" % s
+    st.close()
+
+
 def test_big_golden_n65536(nb):
     """One literal step at N=65536 (configs[1], configs[2] shapes) against the sha256 of the reference's own
     kernel text's output."""
@@ -333,7 +359,7 @@ def test_reference_shaped_launches(nb):
         dev = torch.from_numpy(blk[:6 * n].copy()).cuda()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 11, 12, 14, 18])
+@pytest.mark.parametrize("variant", [0, 1, 11, 12, 14, 18, 40])
 @pytest.mark.parametrize("n,field,steps", [(1000, 5000, 6), (1024, 5000, 6), (130, 1500, 5), (77, 1000, 5),
                                            (4096, 100000, 2)])
 def test_clean_semantics_matches_oracle(nb, n, field, steps, variant):
@@ -519,7 +545,7 @@ def test_error_paths(nb):
         nb.Stepper(cfg, world=2, rank=0)            # RCCL context without a communicator id
     assert e.value.status == -1
     with pytest.raises(nb.NbodyError) as e:
-        nb.Stepper(cfg, semantics=nb.CLEAN, kernel_variant=40)
+        nb.Stepper(cfg, semantics=7)
     assert e.value.status == -1
     st = nb.Stepper(cfg, record_events=True, event_capacity=4)
     with pytest.raises(nb.NbodyError) as e:
