@@ -166,7 +166,9 @@ int nbody_upload(nbody_ctx* ctx, const void* block, int n);
  * compaction), asynchronous: returns after enqueueing. */
 int nbody_step(nbody_ctx* ctx, int nsteps);
 /* cudaMemcpyAsync D2H of the state (src/nbody.cu:486) + the survivors' re-carved block (:496-510):
- * writes 24*n (48*n) bytes laid out for the CURRENT count n and stores n. block must hold `capacity`. */
+ * writes 24*n (48*n) bytes laid out for the CURRENT count n and stores n. block must hold `capacity`.
+ * On an RCCL context (world > 1) this is a COLLECTIVE: velocities live only on their owner, every rank must
+ * call it (the same holds for nbody_state_save, which downloads). */
 int nbody_download(nbody_ctx* ctx, void* block, int* n);
 int nbody_body_count(nbody_ctx* ctx, int* n);   /* synchronises */
 int nbody_sync(nbody_ctx* ctx);                 /* CUDA_SYNC_CHECK (src/nbody.cu:20-33,546)           */
