@@ -189,8 +189,7 @@ void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-template <bool kUnused = false>
-void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
     if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
     else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
@@ -207,7 +206,7 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 12: launch_v3<2>(c, p, nblocks, log); return;
         case 14: launch_v3<4>(c, p, nblocks, log); return;
         case 18: launch_v3<8>(c, p, nblocks, log); return;
-        case 40: launch_pc8<>(c, p, nblocks, log); return;
+        case 40: launch_pc8(c, p, nblocks, log); return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
@@ -215,9 +214,7 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //   >= 80k bodies : one lane per body (4 / 2 waves per SIMD)
     //   below         : 8-wave producer/consumer workgroups per 64 bodies
     if (c->own_upper >= 81920) launch_v3<1>(c, p, nblocks, log);
-    else if (c->desc.semantics == NBODY_LITERAL) launch_pc8<>(c, p, nblocks, log);
-    else if (c->own_upper >= 49152) launch_v3<2>(c, p, nblocks, log);
-    else launch_v3<4>(c, p, nblocks, log);
+    else launch_pc8(c, p, nblocks, log);
 }
 
 template <typename T>
