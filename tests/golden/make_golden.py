@@ -157,6 +157,9 @@ def step_cases():
     # no-collision configuration (radii 0): C2 shape at a size the fixture can hold
     run_case("r0_n2048", ol.ref_init(2048, min_r=0.0, max_r=0.0), 2048, 10, keep=(1, 10))
     run_case("stock_n4096", ol.ref_init(4096), 4096, 6, keep=(1, 6))
+    # the north_star's horizon: 1000 steps (C2/C3 length) at a size the reference shim finishes in a minute,
+    # stock field and radii: bodies keep merging all the way through (2048 -> 741)
+    run_case("long_n2048", ol.ref_init(2048, 100000, 100000), 2048, 1000, keep=(1, 100, 500, 1000))
 
 
 def big_cases():

@@ -245,6 +245,41 @@ def test_headline_size_eight_ranks_equals_one(nb):
     grp.close(); one.close()
 
 
+@pytest.mark.parametrize("radii", ["radii0", "stock"])
+def test_c2_c3_thousand_steps_all_paths_agree(nb, radii):
+    """BASELINE.json configs[1]/[2]: N=65536, 1000 steps, without and with collisions.  The oracle cannot run
+    this horizon in test time; what is checked is (1) step 1 against the golden sha256 from the reference,
+    and (2) after all 1000 steps the automatic kernel, the producer/consumer kernel, the first-generation
+    kernel and a 4-rank range partition hold the same state bit for bit (they share no force code beyond the
+    pair function), with the survivor count shrinking through the kernel-selection and ragged-N regimes."""
+    g = json.load(open(os.path.join(GOLD, "big_n65536.json")))["radii0" if radii == "radii0" else "stock_radii"]
+    kw = {"minRadius": 0.0, "maxRadius": 0.0} if radii == "radii0" else {}
+    cfg = nb.stock_config(particleCount=65536, **kw)
+    bodies = nb.init_bodies(cfg)
+    states = {}
+    for name, variant in (("auto", 0), ("pc8", 40), ("v1", 1)):
+        st = nb.Stepper(cfg, kernel_variant=variant)
+        st.upload(bodies)
+        st.step(1)
+        out = st.download()
+        assert out.numBodies == g["n1"]
+        assert hashlib.sha256(out.block.tobytes()).hexdigest() == g["sha256_post"], name
+        st.step(999)
+        states[name] = st.download()
+        st.close()
+    grp = nb.StepperGroup(4, cfg=cfg)
+    grp.upload(bodies)
+    grp.step(1000)
+    states["group4"] = grp.download()
+    grp.close()
+    ref = states["auto"]
+    if radii == "stock":
+        assert ref.numBodies < g["n1"]
+    for name, out in states.items():
+        assert out.numBodies == ref.numBodies, name
+        assert np.array_equal(bits(out.block), bits(ref.block)), name
+
+
 def test_ragged_large_n_sampled(nb):
     """N = 100 003 (not a multiple of 128: frozen tail, truncated last tile, wrapped cyclic tiles), 2 steps,
     oracle on samples of bodies including the last active block and the frozen tail."""
