@@ -62,11 +62,39 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
     lo = (n // 2 // 128) * 128
     lo = min(lo, n - count)
     t0 = time.perf_counter()
-    *_, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    oP, oV, oM, oR, _, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
     t = time.perf_counter() - t0
-    return {"value": st.pairs / t, "unit": "body-pair-interactions/sec", "cores": threads, "kind": "port",
+    base = {"value": st.pairs / t, "unit": "body-pair-interactions/sec", "cores": threads, "kind": "port",
             "sample": "bodies [%d,%d) of step 1 at N=%d against all j (%d pairs, %.1f s, OpenMP %d threads)" %
                       (lo, lo + count, n, st.pairs, t, threads)}
+    return base, parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR)
+
+
+def parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR):
+    """The second half of BASELINE.json's metric ("max-|dpos| vs ref"): the HIP path's state after step 1
+    against the oracle's for the bodies the CPU leg just computed (outside the timed region).  The device
+    compacts deleted bodies away, so post-step indices are mapped through the device's own deletion log."""
+    import numpy as np
+    st = nb.Stepper(cfg, precision=bodies.precision, record_events=True, event_capacity=1 << 23)
+    st.upload(bodies)
+    st.step(1)
+    out = st.download()
+    ev = st.events()
+    st.close()
+    deleted = np.unique(ev["i"][ev["kind"] == 1]).astype(np.int64)
+    keep = oM != 0
+    pre = lo + np.nonzero(keep)[0]
+    post = pre - np.searchsorted(deleted, pre)
+    same_deleted = np.array_equal(deleted[(deleted >= lo) & (deleted < lo + count)], lo + np.nonzero(~keep)[0])
+    gP, gV, gM, gR = out.Positions[post], out.Velocities[post], out.Masses[post], out.Radii[post]
+    u = np.uint64 if oP.dtype == np.float64 else np.uint32
+    bitwise = bool(same_deleted and all(np.array_equal(np.ascontiguousarray(g).view(u), np.ascontiguousarray(w).view(u))
+                                        for g, w in ((gP, oP[keep]), (gV, oV[keep]), (gM, oM[keep]), (gR, oR[keep]))))
+    return {"against": "CPU oracle, step 1, bodies [%d,%d)" % (lo, lo + count), "bodies": int(count),
+            "deleted_in_sample": int((~keep).sum()), "deleted_sets_equal": bool(same_deleted),
+            "max_abs_dpos": float(np.abs(gP.astype(np.float64) - oP[keep]).max()),
+            "max_abs_dvel": float(np.abs(gV.astype(np.float64) - oV[keep]).max()),
+            "bitwise_equal": bitwise}
 
 
 def main():
@@ -180,7 +208,7 @@ def main():
                               "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": k_pairs},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
         print(json.dumps(out), flush=True)
     st.close()
     if dist is not None:
