@@ -118,6 +118,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # started by hand without a launcher: start one rank per GPU as child processes (nothing in this
+        # process has touched the GPU yet) and leave with the launcher's exit code
+        import socket
+        import subprocess
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch                       # plumbing: rendezvous, barriers, device selection
     import ppa_nbody_collisions_amd as nb
