@@ -634,13 +634,12 @@ int nbody_download(nbody_ctx* c, void* block, int* n_out) {
         HIP_TRY(hipMemcpyAsync(V, c->Vown, (size_t)cnt * 2 * rb, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     } else if (c->comm) {
-        // reuse S_V (cap_own entries) as the send buffer and S_J/gather as the receive area is too small
-        // for vec2 of all ranks in fp64 only if rec_bytes < 2*real_bytes, which never holds (4 vs 2 reals)
+        // padded all-gather of the own velocities into the slot receive area: world * cap_own vec2 entries
+        // always fit there (a slot holds cap_own records of 4 reals, a velocity is 2 reals)
         RCCL_TRY(g_rccl.AllGather(c->Vown, c->gather, (size_t)c->cap_own * 2 * rb, kNcclInt8, c->comm,
                                   c->stream));
-        std::vector<int> counts(c->desc.world);
-        // counts are in the last exchanged slot headers only after a step; recompute from Meta instead:
-        // every rank's lo is the prefix of counts, gathered via a tiny second all-gather of Meta
+        // every rank's {lo, cnt}: a second, tiny all-gather of the device-resident Meta (the slot headers hold
+        // counts only after a step has run)
         Meta* d_all = nullptr;
         HIP_TRY(hipMalloc((void**)&d_all, sizeof(Meta) * c->desc.world));
         RCCL_TRY(g_rccl.AllGather(c->meta, d_all, sizeof(Meta), kNcclInt8, c->comm, c->stream));
