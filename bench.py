@@ -132,6 +132,10 @@ def main():
 
     import torch                       # plumbing: rendezvous, barriers, device selection
     import ppa_nbody_collisions_amd as nb
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    local_rank %= ndev                 # a launcher that exposes one device per rank (HIP_VISIBLE_DEVICES)
 
     comm_id = None
     dist = None
