@@ -237,7 +237,9 @@ void* nbody_ctx_stream(nbody_ctx* ctx);   /* hipStream_t of the context */
  * src/nbody.cu:481-483.  d_bodyData is a device block in the reference layout for numBodies bodies;
  * velocities are updated in place, updatedMasses/updatedRadii are the scratch arrays of :463-464.  The
  * never-allocated `updatedVelocities` argument of the reference (:441) is dropped.  `stream` is a
- * hipStream_t (NULL = default stream).  numBlocks follows :473; pass nbody_num_blocks(numBodies).
+ * hipStream_t (NULL = default stream).  numBlocks follows :473; pass nbody_num_blocks(numBodies): with that
+ * block count the production kernel runs on the block layout (same speed as nbody_step); any other count is
+ * honoured by a general kernel (it changes which bodies are active and how many tiles are walked).
  * ------------------------------------------------------------------------------------------------- */
 int nbody_num_blocks(int numBodies);      /* src/nbody.cu:473 */
 int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updatedMasses, float* d_updatedRadii,

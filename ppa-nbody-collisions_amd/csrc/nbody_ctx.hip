@@ -750,8 +750,18 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_up
     d.timestep = timestep; d.growthRate = growthRate; d.fieldWidth = fieldWidth; d.fieldHeight = fieldHeight;
     d.semantics = NBODY_LITERAL;
     const StepParams<float> p = make_params<float>(d);
-    hipLaunchKernelGGL(ref_layout_forces_f32, dim3(numBlocks), dim3(kTile), 0, (hipStream_t)stream, d_bodyData,
-                       d_updM, d_updR, numBodies, numBlocks, p);
+    const char* force_general = getenv("NBODY_REF_LAUNCH_GENERAL");        // testing aid
+    if (numBlocks == nbody_num_blocks(numBodies) && !(force_general && force_general[0] == '1')) {
+        // the reference's own launch geometry (src/nbody.cu:473): the production kernel on the block layout.
+        // One workgroup per started 128-body block; bodies past the last full block get no thread in the
+        // reference and are left untouched here too.
+        hipLaunchKernelGGL(ref_layout_forces_v3_f32, dim3(numBodies / kTile + 1), dim3(kTile), 0,
+                           (hipStream_t)stream, d_bodyData, d_updM, d_updR, numBodies, p);
+    } else {
+        // any other block count changes which bodies are active and how many tiles are walked: general kernel
+        hipLaunchKernelGGL(ref_layout_forces_f32, dim3(numBlocks), dim3(kTile), 0, (hipStream_t)stream,
+                           d_bodyData, d_updM, d_updR, numBodies, numBlocks, p);
+    }
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }

@@ -296,207 +296,64 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + U, 0xf, 0xf, true));
 }
 
-template <int K, bool kLog>
-__global__ __launch_bounds__(kTile, 4) void forces_v3_f32(const Rec<float>* __restrict__ J,
-                                                       const Vec2<float>* __restrict__ Vown,
-                                                       Rec<float>* __restrict__ S_J,
-                                                       Vec2<float>* __restrict__ S_V,
-                                                       const Meta* __restrict__ meta, StepParams<float> p,
-                                                       Event* ev, int ev_cap, Counters* ctr) {
-    typedef float T;
-    static_assert(K == 1 || K == 2 || K == 4 || K == 8, "K lanes per body");
-    constexpr int kBodies = kTile / K;                     // bodies per workgroup
-    __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
-    __shared__ int tile_bad[2][kTile / kWave];
-    __shared__ int tile_rnz[2][kTile / kWave];            // some radius in the staged tile is not +0
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-    const int lane = threadIdx.x;
-    const int wave = lane / kWave;
-    const int h = lane % K;                                // slice of the walk this lane evaluates
-    const int bl = lane / K;                               // body within the workgroup
-    const int wg = blockIdx.x;
-    const int b = lo / kTile + wg / K;                     // reference block
-    const int t = (wg % K) * kBodies + bl;                 // threadIdx.x of this body in the reference
-    const long long blk0 = (long long)b * kTile;
-    if (blk0 + (wg % K) * kBodies >= (long long)lo + cnt) return;
-    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    // clean semantics (NBODY_CLEAN): every body active, tiles are the plain index ranges 128k..128k+127 in
-    // ascending order, every lane walks a tile from its entry 0, the body itself is skipped by index
-    const bool lit = p.literal != 0;
-    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
-
-    const long long i64 = blk0 + t;
-    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
-    const bool chain = h == 0;                             // lane that owns the accumulators
-    BodyAcc<T> a;
-    Vec2<T> v{0, 0};
-    if (mine) {
-        const Rec<T> me = J[i];
-        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
-        v = Vown[i - lo];
-    } else {
-        a.xi = a.yi = a.mi = a.ri = 0;
-    }
-    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
-    const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
-    const bool wave_ok = __ballot(!lane_ok) == 0ull;
-    // all radii of this wave's bodies are +0.0f: with an all-zero tile the radius sum is exactly +0
-    const bool wave_r0 = __ballot(active && __float_as_uint(a.ri) != 0u) == 0ull;
-    unsigned long long pairs = 0;
-
-    long long start = lit ? blk0 % N : 0;                  // first body of the current tile
-    // lane's entry of the tile starting at body st, or -1 if it has none (N < 128 literal :143; clean tail)
-    auto entry_index = [&](long long st) -> int {
-        long long src = st + lane;
-        if (!lit) return src < N ? (int)src : -1;
-        if (N < kTile && lane >= N) return -1;
-        if (src >= N) src -= N;
-        if (src >= N) src %= N;                            // only when N < 128
-        return (int)src;
-    };
-    auto coord_bad = [](const Rec<T>& r) -> bool {
-        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
-    };
-    {
-        Rec<T> r{0, 0, 0, 0};
-        const int e = entry_index(start);
-        if (e >= 0) { r = J[e]; tile[0][lane] = r; tile[0][lane + kTile] = r; }
-        const bool bad = __ballot(e >= 0 && coord_bad(r)) != 0ull;
-        const bool rnz = __ballot(e >= 0 && __float_as_uint(r.r) != 0u) != 0ull;
-        if ((lane & (kWave - 1)) == 0) { tile_bad[0][wave] = bad; tile_rnz[0][wave] = rnz; }
-    }
-    __syncthreads();
-
-    for (int k = 0; k < ntiles; ++k) {                     // :182, literal: tile k of this body = cyclic tile b + k
-        const int cur = k & 1;
-        const bool have_next = k + 1 < ntiles;
-        long long next_start = start + kTile;
-        if (lit) while (next_start >= N) next_start -= N;
-        Rec<T> nxt{0, 0, 0, 0};
-        const int e_next = have_next ? entry_index(next_start) : -1;
-        if (e_next >= 0) nxt = J[e_next];
-
-        int L;
-        if (lit) L = (k == nb - 1) ? N % (kTile + 1) : kTile;                 // :194 (quirk Q1)
-        else L = (N - start) < kTile ? (int)(N - start) : kTile;
-        // general code on walk positions [o0, o1) of this tile, by the chain lane, exact for every input
-        auto general = [&](int o0, int o1) {
-            if (!(active && chain)) return;
-            const int hi = o1 < L ? o1 : L;
-            for (int off = o0; off < hi; ++off) {
-                int s;
-                long long j;
-                if (lit) {
-                    if (k == 0 && off == 0) continue;                          // :200-204
-                    s = (L == kTile) ? (t + off) : ((t + off) % L);            // :207 (doubled tile: no wrap)
-                    j = start + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
-                    if (j >= N) j %= N;
-                } else {
-                    s = off;
-                    j = start + off;
-                    if (j == i64) continue;
-                }
-                interact<T, kLog>(a, tile[cur][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-            }
-        };
-        bool bad_tile = false;
-#pragma unroll
-        for (int w = 0; w < kTile / kWave; ++w) bad_tile = bad_tile || tile_bad[cur][w] != 0;
-        // tiles whose every position is an ordinary pair for every lane of the workgroup
-        const bool interior = lit ? (k >= 1 && k <= nb - 2) : (L == kTile && k != b);
-        if (interior && wave_ok && !bad_tile) {
-            const Rec<T>* walk = &tile[cur][(lit ? t : 0) + h];   // entry of walk position off = h
-            bool rnz_tile = false;
-#pragma unroll
-            for (int w = 0; w < kTile / kWave; ++w) rnz_tile = rnz_tile || tile_rnz[cur][w] != 0;
-            // kR0: every radius involved is +0.0f, so rs = +0 and q = fma(0, 0, 2^-80) = 2^-80 exactly: the
-            // radius sum and the fma are skipped, the flag test is unchanged
-            auto chunks = [&](auto r0_tag) {
-                constexpr bool kR0 = decltype(r0_tag)::value;
-#pragma unroll 1
-                for (int c = 0; c < kTile / kChunk; ++c) {
-                    const float fx0 = a.fx, fy0 = a.fy;
-                    float fx = fx0, fy = fy0;
-                    unsigned long long flag = 0;
-                    constexpr int kG = (kChunk / K) < 8 ? (kChunk / K) : 8;    // rounds per read batch (4: -5 %, 16: same)
-#pragma unroll 1
-                    for (int r0i = 0; r0i < kChunk / K; r0i += kG) {
-                        // all reads of the batch are issued before any arithmetic: only the first one's latency
-                        // is exposed (hipcc otherwise issues half of them right before their use)
-                        Rec<T> rec[kG];
-#pragma unroll
-                        for (int u = 0; u < kG; ++u) rec[u] = walk[c * kChunk + (r0i + u) * K];
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int u = 0; u < kG; ++u) {
-                            const Rec<T> bj = rec[u];
-                            const float dx = bj.x - a.xi;
-                            const float dy = bj.y - a.yi;
-                            const float d2 = (dx * dx) + (dy * dy);
-                            float q = kFastLo;
-                            if (!kR0) {
-                                const float rs = a.ri + bj.r;
-                                q = __builtin_fmaf(rs, rs, kFastLo);           // flag only
-                            }
-                            flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
-                            const FastChain ch = fast_chain(d2);
-                            const float tx = ch.inv * (bj.m * dx);
-                            const float ty = ch.inv * (bj.m * dy);
-                            fx = fx + tx;                   // walk position r*K + 0
-                            fy = fy + ty;
-                            if (K > 1) { fx = fx + dpp_row_shl<1>(tx); fy = fy + dpp_row_shl<1>(ty); }
-                            if (K > 2) { fx = fx + dpp_row_shl<2>(tx); fy = fy + dpp_row_shl<2>(ty);
-                                         fx = fx + dpp_row_shl<3>(tx); fy = fy + dpp_row_shl<3>(ty); }
-                            if (K > 4) { fx = fx + dpp_row_shl<4>(tx); fy = fy + dpp_row_shl<4>(ty);
-                                         fx = fx + dpp_row_shl<5>(tx); fy = fy + dpp_row_shl<5>(ty);
-                                         fx = fx + dpp_row_shl<6>(tx); fy = fy + dpp_row_shl<6>(ty);
-                                         fx = fx + dpp_row_shl<7>(tx); fy = fy + dpp_row_shl<7>(ty); }
-                        }
-                    }
-                    if (flag == 0ull) {
-                        a.fx = fx; a.fy = fy;
-                    } else {   // a collision / tiny distance somewhere in this wave's chunk: redo it exactly
-                        a.fx = fx0; a.fy = fy0;
-                        general(c * kChunk, c * kChunk + kChunk);
-                    }
-                }
-            };
-            if (wave_r0 && !rnz_tile) chunks(std::true_type{});
-            else chunks(std::false_type{});
-        } else {
-            general(0, L);
-        }
-        if (active && chain) {
-            if (lit) pairs += (k == 0) ? (L > 0 ? L - 1 : 0) : L;
-            else pairs += L - ((i64 >= start && i64 < start + L) ? 1 : 0);
-        }
-        if (have_next) {
-            if (e_next >= 0) { tile[cur ^ 1][lane] = nxt; tile[cur ^ 1][lane + kTile] = nxt; }
-            const bool bad = __ballot(e_next >= 0 && coord_bad(nxt)) != 0ull;
-            const bool rnz = __ballot(e_next >= 0 && __float_as_uint(nxt.r) != 0u) != 0ull;
-            if ((lane & (kWave - 1)) == 0) { tile_bad[cur ^ 1][wave] = bad; tile_rnz[cur ^ 1][wave] = rnz; }
-        }
-        __syncthreads();
-        start = next_start;
-    }
-
-    if (mine && chain) {
-        const int q = i - lo;
-        if (active) {
-            Rec<T> out; Vec2<T> vout;
-            finish_body<T>(a, v, p, out, vout);
-            S_J[q] = out;
-            S_V[q] = vout;
-        } else {       // frozen body: no thread exists for it in the reference, state carried over unchanged
-            S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
-            S_V[q] = v;
-        }
-    }
-    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
+#define NB_V3_SIGNATURE                                                                                      \
+    template <int K, bool kLog>                                                                              \
+    __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(                                               \
+        const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown, Rec<float>* __restrict__ S_J, \
+        Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta, StepParams<float> p, Event* ev,        \
+        int ev_cap, Counters* ctr)
+#define NB_V3_CONSTANTS
+#define NB_V3_RANGE const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+#define NB_V3_REC(j) J[j]
+#define NB_V3_VEL(i) Vown[i - lo]
+#define NB_V3_PUT(q, i, out, vout) S_J[q] = out; S_V[q] = vout;
+#define NB_V3_KEEP(q, i, a, v) S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri}; S_V[q] = v;
+#define NB_V3_COUNT(pairs)                                                                                   \
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
     if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
-}
+#include "nbody_forces_v3.inc"
+#undef NB_V3_SIGNATURE
+#undef NB_V3_CONSTANTS
+#undef NB_V3_RANGE
+#undef NB_V3_REC
+#undef NB_V3_VEL
+#undef NB_V3_PUT
+#undef NB_V3_KEEP
+#undef NB_V3_COUNT
+
+// The same kernel on the reference's device block [P|V|M|R] and its two scratch arrays: drop-in for the
+// ComputeForces<<<>>> site when it is launched with the reference's own block count (src/nbody.cu:473,481-482).
+// Velocities are updated in place (:264), updatedMasses / updatedRadii written (:245-246), positions are left to
+// MoveBodies, bodies without a thread in the reference are not touched.
+#define NB_V3_SIGNATURE                                                                                      \
+    __global__ __launch_bounds__(kTile, 4) void ref_layout_forces_v3_f32(                                    \
+        void* bodyData, float* __restrict__ updM, float* __restrict__ updR, const int N, StepParams<float> p)
+#define NB_V3_CONSTANTS                                                                                      \
+    constexpr int K = 1;                                                                                     \
+    constexpr bool kLog = false;
+#define NB_V3_RANGE                                                                                          \
+    constexpr int lo = 0, step = 0, ev_cap = 0;                                                              \
+    const int cnt = N;                                                                                       \
+    Event* const ev = nullptr;                                                                               \
+    Counters* const ctr = nullptr;                                                                           \
+    const Vec2<float>* __restrict__ P = reinterpret_cast<const Vec2<float>*>(bodyData); /* :147-150 */       \
+    Vec2<float>* __restrict__ V = reinterpret_cast<Vec2<float>*>(bodyData) + N;                              \
+    const float* __restrict__ M = reinterpret_cast<const float*>(V + N);                                     \
+    const float* __restrict__ R = M + N;
+#define NB_V3_REC(j) Rec<float>{P[j].x, P[j].y, M[j], R[j]}
+#define NB_V3_VEL(i) V[i]
+#define NB_V3_PUT(q, i, out, vout) (void)q; updM[i] = out.m; updR[i] = out.r; V[i] = vout;
+#define NB_V3_KEEP(q, i, a, v) (void)q;
+#define NB_V3_COUNT(pairs) (void)pairs;
+#include "nbody_forces_v3.inc"
+#undef NB_V3_SIGNATURE
+#undef NB_V3_CONSTANTS
+#undef NB_V3_RANGE
+#undef NB_V3_REC
+#undef NB_V3_VEL
+#undef NB_V3_PUT
+#undef NB_V3_KEEP
+#undef NB_V3_COUNT
 
 // ---------------------------------------------------------------------------------------------------------
 // Force + collision + drift kernel, variant "pc8" (fp32, producer / consumer): for ranks that own far fewer

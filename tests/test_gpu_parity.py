@@ -363,16 +363,22 @@ def test_full_size_sampled_parity_n262144(nb):
     st.close()
 
 
-def test_reference_shaped_launches(nb):
+@pytest.mark.parametrize("general", [False, True], ids=["production-kernel", "general-kernel"])
+@pytest.mark.parametrize("path", [p for p in STEP_FILES if "long_" not in p],
+                         ids=[os.path.basename(p)[6:-4] for p in STEP_FILES if "long_" not in p])
+def test_reference_shaped_launches(nb, path, general, monkeypatch):
     """nbody_launch_compute_forces_f32 / nbody_launch_move_bodies_f32 on a caller-owned device block in the
-    reference layout (drop-in for src/nbody.cu:481-483); device memory comes from torch."""
+    reference layout (drop-in for src/nbody.cu:481-483), followed by the host compaction, on every golden case;
+    device memory comes from torch.  With the reference's own block count the launch runs the production kernel
+    on the block layout; NBODY_REF_LAUNCH_GENERAL=1 forces the general kernel that serves other block counts."""
     import torch
-    z = np.load(os.path.join(GOLD, "steps_dense_n1000.npz"))
+    monkeypatch.setenv("NBODY_REF_LAUNCH_GENERAL", "1" if general else "0")
+    z = np.load(path)
     dt, growth, fw, fh = z["params"]
-    n = 1000
+    n = int(z["n0"])
     host = z["init"].view(np.float32).copy()
     dev = torch.from_numpy(host.copy()).cuda()
-    for s in range(1, 6):
+    for s in range(1, min(len(z["counts"]), 12) + 1):
         upd_m = dev[4 * n:5 * n].clone()      # src/nbody.cu:467-470
         upd_r = dev[5 * n:6 * n].clone()
         blocks = nb.lib.nbody_num_blocks(n)
