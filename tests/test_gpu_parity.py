@@ -206,6 +206,24 @@ def test_sharded_group_equals_single(nb, world):
     grp.close()
 
 
+@pytest.mark.parametrize("case", ["three_body", "edge_n1", "edge_n2", "edge_n129", "edge_n130"])
+def test_more_ranks_than_work(nb, case):
+    """8 ranks over 1, 2, 3 bodies (most ranks own nothing) and over the N=129/130 quirk cases."""
+    z = np.load(os.path.join(GOLD, "steps_%s.npz" % case))
+    dt, growth, fw, fh = z["params"]
+    n0 = int(z["n0"])
+    grp = nb.StepperGroup(8, capacity=n0, timestep=float(dt), growthRate=float(growth), fieldWidth=int(fw),
+                          fieldHeight=int(fh))
+    grp.upload(nb.BodiesData.from_block(z["init"].view(np.float32), n0))
+    for s in range(1, len(z["counts"]) + 1):
+        grp.step(1)
+        if "after_%d" % s in z:
+            assert_bodies_equal(grp.download(), z["after_%d" % s].view(np.float32), int(z["counts"][s - 1]),
+                                "%s step %d" % (case, s))
+    assert sum(r.own_range()[1] for r in grp.ranks) == int(z["counts"][-1])
+    grp.close()
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_big_golden_n65536_sharded(nb, world):
     """The N=65536 stock-radii golden (10 095 deletions in one step) through a `world`-rank partition with the
