@@ -103,6 +103,43 @@ def test_events_match_oracle(nb, n, field, steps):
     st.close()
 
 
+def test_random_small_cases_match_oracle(nb):
+    """Seeded random sweep over the awkward part of the parameter space: N in 1..700 (all the N < 128,
+    129..255 and non-multiple-of-128 quirks, counts that shrink across those boundaries), dense fields, random
+    radius / mass ranges, literal and clean semantics, fp32 and fp64, every kernel variant, 1..4 ranks.  Bit-exact against the
+    oracle after every step."""
+    rng = np.random.default_rng(20240611)
+    for case in range(150):
+        n = int(rng.choice([rng.integers(1, 128), rng.integers(128, 260), rng.integers(260, 700)]))
+        field = int(rng.choice([300, 1000, 3000, 20000]))
+        min_r = float(rng.choice([0.0, 1.0, 10.0]))
+        max_r = min_r + float(rng.choice([0.0, 5.0, 60.0]))
+        max_m = float(rng.choice([1e5, 1e12, 1e17]))
+        sem = int(rng.integers(0, 2))
+        variant = int(rng.choice(VARIANTS))
+        world = int(rng.integers(1, 5))
+        f64 = bool(rng.integers(0, 5) == 0)
+        cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=min_r,
+                              maxRadius=max_r, maxRandBodyMass=max_m)
+        bodies = nb.init_bodies(cfg, nb.F64 if f64 else nb.F32)
+        bodies.Velocities[:] = rng.uniform(-50, 50, size=(n, 2)).astype(bodies.Velocities.dtype)   # walls matter
+        grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant,
+                              precision=nb.F64 if f64 else nb.F32)
+        grp.upload(bodies)
+        blk = bodies.contiguousData.copy()
+        cur = n
+        dt, gr = (float(DT), float(GROWTH)) if f64 else (DT, GROWTH)
+        what = "case %d: n=%d field=%d r=[%g,%g] m<=%g sem=%d variant=%d world=%d f64=%d" % (
+            case, n, field, min_r, max_r, max_m, sem, variant, world, f64)
+        for s in range(5):
+            grp.step(1)
+            cur, *_ = ol.port_step(blk, cur, dt, field, field, gr, semantics=sem, want_events=False)
+            assert_bodies_equal(grp.download(), blk, cur, "%s step %d" % (what, s))
+            if cur == 0:
+                break
+        grp.close()
+
+
 def _nan_aware_equal(got, want):
     g, w = np.asarray(got), np.asarray(want)
     both_nan = np.isnan(g) & np.isnan(w)
