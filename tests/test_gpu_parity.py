@@ -140,6 +140,31 @@ def test_random_small_cases_match_oracle(nb):
         grp.close()
 
 
+def test_random_medium_cases_match_oracle(nb):
+    """Seeded random sweep at sizes where most tiles take the fast evaluation path (N 2 000..20 000, not multiples
+    of 128, collisions scattered through the walk so flagged chunks / sub-tiles are redone by the general code)."""
+    rng = np.random.default_rng(77)
+    for case in range(14):
+        n = int(rng.integers(2000, 20000))
+        field = int(rng.choice([20000, 60000, 100000]))
+        max_r = float(rng.choice([0.0, 30.0, 200.0]))
+        sem = int(rng.integers(0, 2))
+        variant = int(rng.choice(VARIANTS))
+        world = int(rng.choice([1, 1, 2, 3]))
+        cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=0.0, maxRadius=max_r)
+        bodies = nb.init_bodies(cfg)
+        grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant)
+        grp.upload(bodies)
+        blk = bodies.contiguousData.copy()
+        cur = n
+        for s in range(3):
+            grp.step(1)
+            cur, *_ = ol.port_step(blk, cur, DT, field, field, GROWTH, semantics=sem, want_events=False)
+            assert_bodies_equal(grp.download(), blk, cur, "case %d: n=%d field=%d max_r=%g sem=%d variant=%d "
+                                "world=%d step %d" % (case, n, field, max_r, sem, variant, world, s))
+        grp.close()
+
+
 def _nan_aware_equal(got, want):
     g, w = np.asarray(got), np.asarray(want)
     both_nan = np.isnan(g) & np.isnan(w)
