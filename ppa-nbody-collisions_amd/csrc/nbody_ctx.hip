@@ -168,7 +168,9 @@ int read_meta(nbody_ctx* c) {
 }
 
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
-//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body | 40 pc8 (producer/consumer)
+//                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body, 128-thread workgroups |
+//                 31,32 v3 K = 1 with 256-thread workgroups, registers sized for 4 / 2 waves per SIMD |
+//                 40 pc8 (producer/consumer)
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -189,6 +191,13 @@ void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) 
     else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
+template <int K, int kOcc>
+void launch_v3w(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = (nblocks * K + 1) / 2;                // two 128-lane groups per workgroup
+    if (log) hipLaunchKernelGGL((forces_v3w_f32<K, true, kOcc>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_v3w_f32<K, false, kOcc>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(float));
+}
+
 inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
     if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
@@ -206,14 +215,18 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 12: launch_v3<2>(c, p, nblocks, log); return;
         case 14: launch_v3<4>(c, p, nblocks, log); return;
         case 18: launch_v3<8>(c, p, nblocks, log); return;
+        case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
+        case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
         case 40: launch_pc8(c, p, nblocks, log); return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
     // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144, profiles/r01_scaling_probe_*.txt):
-    //   >= 80k bodies : one lane per body (4 / 2 waves per SIMD)
-    //   below         : 8-wave producer/consumer workgroups per 64 bodies
-    if (c->own_upper >= 81920) launch_v3<1>(c, p, nblocks, log);
+    //   >= 200k bodies : one lane per body, 256-thread workgroups, 4 waves per SIMD
+    //   >= 80k bodies  : the same with the register budget of 2 waves per SIMD
+    //   below          : 8-wave producer/consumer workgroups per 64 bodies
+    if (c->own_upper >= 200000) launch_v3w<1, 4>(c, p, nblocks, log);
+    else if (c->own_upper >= 81920) launch_v3w<1, 2>(c, p, nblocks, log);
     else launch_pc8(c, p, nblocks, log);
 }
 
@@ -382,8 +395,12 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
     CTX_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
     CTX_TRY(hipMalloc((void**)&c->events, sizeof(Event) * (size_t)c->ev_cap));
-    CTX_TRY(hipMemset(c->counters, 0, sizeof(Counters)));
-    CTX_TRY(hipMemset(c->meta, 0, sizeof(Meta)));
+    // on the context's own stream and waited for: hipMemset() on device memory runs on the NULL stream and may
+    // return before the fill has executed; the context's stream is non-blocking, so a late fill could land
+    // after nbody_upload's copy of Meta (seen once as a step that found n = 0)
+    CTX_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
+    CTX_TRY(hipMemsetAsync(c->meta, 0, sizeof(Meta), c->stream));
+    CTX_TRY(hipStreamSynchronize(c->stream));
     c->h_stage_bytes = (size_t)c->cap * c->rec_bytes;
     CTX_TRY(hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
     CTX_TRY(hipHostMalloc((void**)&c->h_meta, sizeof(Meta), hipHostMallocDefault));
@@ -753,9 +770,9 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_up
     const char* force_general = getenv("NBODY_REF_LAUNCH_GENERAL");        // testing aid
     if (numBlocks == nbody_num_blocks(numBodies) && !(force_general && force_general[0] == '1')) {
         // the reference's own launch geometry (src/nbody.cu:473): the production kernel on the block layout.
-        // One workgroup per started 128-body block; bodies past the last full block get no thread in the
+        // One 128-lane group per started 128-body block (two per workgroup); bodies past the last full block get no thread in the
         // reference and are left untouched here too.
-        hipLaunchKernelGGL(ref_layout_forces_v3_f32, dim3(numBodies / kTile + 1), dim3(kTile), 0,
+        hipLaunchKernelGGL(ref_layout_forces_v3_f32, dim3((numBodies / kTile + 2) / 2), dim3(2 * kTile), 0,
                            (hipStream_t)stream, d_bodyData, d_updM, d_updR, numBodies, p);
     } else {
         // any other block count changes which bodies are active and how many tiles are walked: general kernel

@@ -302,6 +302,13 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
         const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown, Rec<float>* __restrict__ S_J, \
         Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta, StepParams<float> p, Event* ev,        \
         int ev_cap, Counters* ctr)
+#define NB_V3_LDS                                                                                            \
+    __shared__ Rec<T> tile[2][2 * kTile];                  /* each tile stored twice: no wrap in the walk */ \
+    __shared__ int tile_bad[2][kTile / kWave];                                                               \
+    __shared__ int tile_rnz[2][kTile / kWave];             /* some radius in the staged tile is not +0 */
+#define NB_V3_LANE const int lane = threadIdx.x;
+#define NB_V3_WG const int wg = blockIdx.x;
+#define NB_V3_BATCH 8
 #define NB_V3_CONSTANTS
 #define NB_V3_RANGE const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
 #define NB_V3_REC(j) J[j]
@@ -313,6 +320,10 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
     if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 #include "nbody_forces_v3.inc"
 #undef NB_V3_SIGNATURE
+#undef NB_V3_LDS
+#undef NB_V3_LANE
+#undef NB_V3_WG
+#undef NB_V3_BATCH
 #undef NB_V3_CONSTANTS
 #undef NB_V3_RANGE
 #undef NB_V3_REC
@@ -321,13 +332,69 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
 #undef NB_V3_KEEP
 #undef NB_V3_COUNT
 
-// The same kernel on the reference's device block [P|V|M|R] and its two scratch arrays: drop-in for the
-// ComputeForces<<<>>> site when it is launched with the reference's own block count (src/nbody.cu:473,481-482).
-// Velocities are updated in place (:264), updatedMasses / updatedRadii written (:245-246), positions are left to
-// MoveBodies, bodies without a thread in the reference are not touched.
+// The same kernel with 256-thread workgroups: two independent 128-lane groups (each one reference block or a
+// K-th of it, each with its own tiles) share a workgroup and its barriers, so that a workgroup has four waves and
+// the dispatcher puts one on every SIMD (two 2-wave workgroups per CU land 2-1-1-0,
+// profiles/r01_wave_placement.txt), and 16 instead of 8 tile reads are in flight per batch.  kOcc = waves per SIMD
+// the register budget is sized for: 4 (118 VGPRs) when the own range fills the chip, 2 (130 VGPRs) below.
+// Same-box A/B at N=262144 against the 128-thread kernel: 37.95 vs 38.92 ms (1 rank), 21.3 vs 22.5 ms per rank
+// (2 ranks).  This is the one-lane-per-body production kernel.
 #define NB_V3_SIGNATURE                                                                                      \
-    __global__ __launch_bounds__(kTile, 4) void ref_layout_forces_v3_f32(                                    \
+    template <int K, bool kLog, int kOcc>                                                                    \
+    __global__ __launch_bounds__(2 * kTile, kOcc) void forces_v3w_f32(                                       \
+        const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown, Rec<float>* __restrict__ S_J, \
+        Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta, StepParams<float> p, Event* ev,        \
+        int ev_cap, Counters* ctr)
+#define NB_V3_LDS                                                                                            \
+    __shared__ Rec<T> tile_all[2][2][2 * kTile];                                                             \
+    __shared__ int tile_bad_all[2][2][kTile / kWave];                                                        \
+    __shared__ int tile_rnz_all[2][2][kTile / kWave];                                                        \
+    Rec<T>(&tile)[2][2 * kTile] = tile_all[threadIdx.x / kTile];                                             \
+    int(&tile_bad)[2][kTile / kWave] = tile_bad_all[threadIdx.x / kTile];                                    \
+    int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
+#define NB_V3_LANE const int lane = threadIdx.x % kTile;
+#define NB_V3_WG const int wg = blockIdx.x * 2 + threadIdx.x / kTile;
+#define NB_V3_BATCH 16
+#define NB_V3_CONSTANTS
+#define NB_V3_RANGE const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+#define NB_V3_REC(j) J[j]
+#define NB_V3_VEL(i) Vown[i - lo]
+#define NB_V3_PUT(q, i, out, vout) S_J[q] = out; S_V[q] = vout;
+#define NB_V3_KEEP(q, i, a, v) S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri}; S_V[q] = v;
+#define NB_V3_COUNT(pairs)                                                                                   \
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
+    if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
+#include "nbody_forces_v3.inc"
+#undef NB_V3_SIGNATURE
+#undef NB_V3_LDS
+#undef NB_V3_LANE
+#undef NB_V3_WG
+#undef NB_V3_BATCH
+#undef NB_V3_CONSTANTS
+#undef NB_V3_RANGE
+#undef NB_V3_REC
+#undef NB_V3_VEL
+#undef NB_V3_PUT
+#undef NB_V3_KEEP
+#undef NB_V3_COUNT
+
+// The same kernel (256-thread form) on the reference's device block [P|V|M|R] and its two scratch arrays: drop-in
+// for the ComputeForces<<<>>> site when it is launched with the reference's own block count
+// (src/nbody.cu:473,481-482).  Velocities are updated in place (:264), updatedMasses / updatedRadii written
+// (:245-246), positions are left to MoveBodies, bodies without a thread in the reference are not touched.
+#define NB_V3_SIGNATURE                                                                                      \
+    __global__ __launch_bounds__(2 * kTile, 4) void ref_layout_forces_v3_f32(                                \
         void* bodyData, float* __restrict__ updM, float* __restrict__ updR, const int N, StepParams<float> p)
+#define NB_V3_LDS                                                                                            \
+    __shared__ Rec<T> tile_all[2][2][2 * kTile];                                                             \
+    __shared__ int tile_bad_all[2][2][kTile / kWave];                                                        \
+    __shared__ int tile_rnz_all[2][2][kTile / kWave];                                                        \
+    Rec<T>(&tile)[2][2 * kTile] = tile_all[threadIdx.x / kTile];                                             \
+    int(&tile_bad)[2][kTile / kWave] = tile_bad_all[threadIdx.x / kTile];                                    \
+    int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
+#define NB_V3_LANE const int lane = threadIdx.x % kTile;
+#define NB_V3_WG const int wg = blockIdx.x * 2 + threadIdx.x / kTile;
+#define NB_V3_BATCH 16
 #define NB_V3_CONSTANTS                                                                                      \
     constexpr int K = 1;                                                                                     \
     constexpr bool kLog = false;
@@ -347,6 +414,10 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
 #define NB_V3_COUNT(pairs) (void)pairs;
 #include "nbody_forces_v3.inc"
 #undef NB_V3_SIGNATURE
+#undef NB_V3_LDS
+#undef NB_V3_LANE
+#undef NB_V3_WG
+#undef NB_V3_BATCH
 #undef NB_V3_CONSTANTS
 #undef NB_V3_RANGE
 #undef NB_V3_REC

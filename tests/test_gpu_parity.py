@@ -47,7 +47,7 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-VARIANTS = [0, 1, 11, 12, 14, 18, 40]   # automatic | v1 | v3 K=1,2,4,8 | pc8 (csrc/nbody_ctx.hip)
+VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40]   # automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -480,7 +480,7 @@ def test_reference_shaped_launches(nb, path, general, monkeypatch):
         dev = torch.from_numpy(blk[:6 * n].copy()).cuda()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 11, 12, 14, 18, 40])
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("n,field,steps", [(1000, 5000, 6), (1024, 5000, 6), (130, 1500, 5), (77, 1000, 5),
                                            (4096, 100000, 2)])
 def test_clean_semantics_matches_oracle(nb, n, field, steps, variant):
