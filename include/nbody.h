@@ -152,7 +152,8 @@ typedef struct nbody_ctx_desc {
     const void* comm_id;    /* world>1 with RCCL: 128-byte id from nbody_comm_unique_id on rank 0       */
     int kernel_variant;     /* 0 = automatic (by own-range size); tuning / A-B testing only: 1 general kernel, */
                             /* 11/12/14/18 one-lane..eight-lanes-per-body kernel, 31/32 its 256-thread form,   */
-                            /* 40 producer/consumer kernel                                                      */
+                            /* 40 producer/consumer kernel.  fp64: 1 selects the general kernel, anything else  */
+                            /* the fp64 production kernel                                                       */
 } nbody_ctx_desc;
 
 void nbody_ctx_desc_from_config(nbody_ctx_desc* d, const nbody_config* cfg, int precision);
@@ -254,6 +255,10 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updatedMasses,
  * (rsq/rcp + fma corrections) against the general code on its whole guarded domain.
  * mismatches = {sqrt, reciprocal, fast chain} mismatch counts; all must be 0. */
 int nbody_selftest_ieee_f32(int device, uint64_t mismatches[3]);
+/* The fp64 counterpart cannot be exhaustive: the fast chain of the fp64 force kernel against the compiler's IEEE
+ * sqrt and 1/x on inputs_per_mode inputs of each of three families of its guarded domain [2^-500, 2^500] (random;
+ * mantissas next to powers of two; perfect squares +- 4 ulps).  mismatches = {sqrt, 1/d^3}; both must be 0. */
+int nbody_selftest_chain_f64(int device, uint64_t inputs_per_mode, uint64_t mismatches[2]);
 
 #ifdef __cplusplus
 }

@@ -180,8 +180,14 @@ void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
 template <>
 void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblocks, bool log) {
-    if (log) hipLaunchKernelGGL((forces_v1<double, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
-    else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
+    if (c->desc.kernel_variant == 1) {                     // general kernel: compiler IEEE sqrt / divide per pair
+        if (log) hipLaunchKernelGGL((forces_v1<double, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
+        else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
+        return;
+    }
+    const int grid = (nblocks + 1) / 2;                    // two 128-lane groups per workgroup
+    if (log) hipLaunchKernelGGL((forces_v3w_f64<true>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
+    else hipLaunchKernelGGL((forces_v3w_f64<false>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
 }
 
 template <int K>
@@ -810,6 +816,30 @@ int nbody_selftest_ieee_f32(int device, uint64_t mismatches[3]) {
     mismatches[0] = h[0];
     mismatches[1] = h[1];
     mismatches[2] = h[2];
+    return NBODY_OK;
+}
+
+int nbody_selftest_chain_f64(int device, uint64_t inputs_per_mode, uint64_t mismatches[2]) {
+    if (!mismatches || inputs_per_mode == 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_selftest_chain_f64: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return nbody_fail(NBODY_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), 0));
+    const int blocks = 4096;
+    const uint64_t per_thread = (inputs_per_mode + (uint64_t)blocks * 256 - 1) / ((uint64_t)blocks * 256);
+    const int iters = per_thread > 0x7fffffff ? 0x7fffffff : (int)per_thread;
+    for (int mode = 0; mode < 3; ++mode)
+        hipLaunchKernelGGL(selftest_chain_f64, dim3(blocks), dim3(256), 0, 0, d, mode, iters,
+                           0xabcdefull + (unsigned long long)mode);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(d);
+    mismatches[0] = h[0];
+    mismatches[1] = h[1];
     return NBODY_OK;
 }
 

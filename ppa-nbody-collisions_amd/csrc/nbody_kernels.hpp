@@ -274,6 +274,53 @@ __device__ __forceinline__ FastChain fast_chain(float d2) {
     return FastChain{d, __builtin_fmaf(e2, r, r)};
 }
 
+// fp64 counterpart.  The steps are the ones hipcc's own correctly-rounded fp64 sqrt and divide expansions perform
+// between their range scaling (v_ldexp / v_div_scale) and their special-case fix-ups (v_div_fixup, class tests):
+// for operands whose exponents keep every intermediate normal - d2 in [2^-500, 2^500], hence d^3 in
+// [2^-750, 2^750] - the scaling is by 2^0 and the fix-ups select the computed value, so the results are the same
+// bits.  Checked on the device against the compiler's sqrt and 1/x (csrc/tune/chain_probe_f64.hip: 1.3e10 random
+// and structured inputs; nbody_selftest_chain_f64 in the test-suite).  36 instead of 71 instructions per pair.
+struct FastChainD { double d, inv; };
+__device__ __forceinline__ FastChainD fast_chain(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g0 = x * y;
+    const double h0 = 0.5 * y;
+    const double r0 = __builtin_fma(-h0, g0, 0.5);
+    const double g1 = __builtin_fma(g0, r0, g0);
+    const double h1 = __builtin_fma(h0, r0, h0);
+    const double d0 = __builtin_fma(-g1, g1, x);
+    const double g2 = __builtin_fma(d0, h1, g1);
+    const double d1 = __builtin_fma(-g2, g2, x);
+    const double d = __builtin_fma(d1, h1, g2);
+    const double c = (d * d) * d;
+    const double q0 = __builtin_amdgcn_rcp(c);
+    const double e0 = __builtin_fma(-c, q0, 1.0);
+    const double q1 = __builtin_fma(q0, e0, q0);
+    const double e1 = __builtin_fma(-c, q1, 1.0);
+    const double q2 = __builtin_fma(q1, e1, q1);
+    const double e2 = __builtin_fma(-c, q2, 1.0);
+    return FastChainD{d, __builtin_fma(e2, q2, q2)};
+}
+
+// the guarded domain of the fast chains per precision: pairs with d2 <= fma(rs, rs, lo) or a coordinate at or beyond
+// `coord` (so d2 could exceed the upper edge) are left to the general code
+template <typename T> struct FastDomain;
+template <> struct FastDomain<float> { static constexpr float lo = kFastLo, coord = kCoordBound; };
+template <> struct FastDomain<double> { static constexpr double lo = 0x1p-500, coord = 0x1p249; };
+
+__device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double abs_(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ unsigned long long le_mask(float a, float b) {     // wave mask of a <= b (ordered)
+    return __builtin_amdgcn_fcmpf(a, b, 5 /* llvm::CmpInst::FCMP_OLE */);
+}
+__device__ __forceinline__ unsigned long long le_mask(double a, double b) {
+    return __builtin_amdgcn_fcmp(a, b, 5 /* llvm::CmpInst::FCMP_OLE */);
+}
+__device__ __forceinline__ bool not_plus_zero(float x) { return __float_as_uint(x) != 0u; }
+__device__ __forceinline__ bool not_plus_zero(double x) { return __double_as_longlong(x) != 0ll; }
+
 // ---------------------------------------------------------------------------------------------------------
 // Force + collision + drift kernel, variant "v3" (fp32): the production kernel.
 //
@@ -295,7 +342,15 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
     // bound_ctrl:1 (out-of-row lanes read 0) lets the DPP combiner fold the move into the consuming v_add_f32
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x100 + U, 0xf, 0xf, true));
 }
+template <int U>
+__device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 only; present so the text compiles
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)b, 0x100 + U, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), 0x100 + U, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
 
+#define NB_V3_REAL float
 #define NB_V3_SIGNATURE                                                                                      \
     template <int K, bool kLog>                                                                              \
     __global__ __launch_bounds__(kTile, 4) void forces_v3_f32(                                               \
@@ -319,6 +374,7 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
     for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
     if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 #include "nbody_forces_v3.inc"
+#undef NB_V3_REAL
 #undef NB_V3_SIGNATURE
 #undef NB_V3_LDS
 #undef NB_V3_LANE
@@ -339,6 +395,7 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
 // the register budget is sized for: 4 (118 VGPRs) when the own range fills the chip, 2 (130 VGPRs) below.
 // Same-box A/B at N=262144 against the 128-thread kernel: 37.95 vs 38.92 ms (1 rank), 21.3 vs 22.5 ms per rank
 // (2 ranks).  This is the one-lane-per-body production kernel.
+#define NB_V3_REAL float
 #define NB_V3_SIGNATURE                                                                                      \
     template <int K, bool kLog, int kOcc>                                                                    \
     __global__ __launch_bounds__(2 * kTile, kOcc) void forces_v3w_f32(                                       \
@@ -365,6 +422,50 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
     for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
     if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 #include "nbody_forces_v3.inc"
+#undef NB_V3_REAL
+#undef NB_V3_SIGNATURE
+#undef NB_V3_LDS
+#undef NB_V3_LANE
+#undef NB_V3_WG
+#undef NB_V3_BATCH
+#undef NB_V3_CONSTANTS
+#undef NB_V3_RANGE
+#undef NB_V3_REC
+#undef NB_V3_VEL
+#undef NB_V3_PUT
+#undef NB_V3_KEEP
+#undef NB_V3_COUNT
+
+// The same kernel in fp64 (256-thread form, one lane per body): the fp64 production kernel.  A record is 32 bytes,
+// 8 reads per batch (same-box A/B: 4 reads with the 4-waves register budget -0.4 %, 16 reads -4 %).
+#define NB_V3_REAL double
+#define NB_V3_SIGNATURE                                                                                      \
+    template <bool kLog>                                                                                     \
+    __global__ __launch_bounds__(2 * kTile, 2) void forces_v3w_f64(                                          \
+        const Rec<double>* __restrict__ J, const Vec2<double>* __restrict__ Vown,                            \
+        Rec<double>* __restrict__ S_J, Vec2<double>* __restrict__ S_V, const Meta* __restrict__ meta,        \
+        StepParams<double> p, Event* ev, int ev_cap, Counters* ctr)
+#define NB_V3_LDS                                                                                            \
+    __shared__ Rec<T> tile_all[2][2][2 * kTile];                                                             \
+    __shared__ int tile_bad_all[2][2][kTile / kWave];                                                        \
+    __shared__ int tile_rnz_all[2][2][kTile / kWave];                                                        \
+    Rec<T>(&tile)[2][2 * kTile] = tile_all[threadIdx.x / kTile];                                             \
+    int(&tile_bad)[2][kTile / kWave] = tile_bad_all[threadIdx.x / kTile];                                    \
+    int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
+#define NB_V3_LANE const int lane = threadIdx.x % kTile;
+#define NB_V3_WG const int wg = blockIdx.x * 2 + threadIdx.x / kTile;
+#define NB_V3_BATCH 8
+#define NB_V3_CONSTANTS constexpr int K = 1;
+#define NB_V3_RANGE const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+#define NB_V3_REC(j) J[j]
+#define NB_V3_VEL(i) Vown[i - lo]
+#define NB_V3_PUT(q, i, out, vout) S_J[q] = out; S_V[q] = vout;
+#define NB_V3_KEEP(q, i, a, v) S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri}; S_V[q] = v;
+#define NB_V3_COUNT(pairs)                                                                                   \
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
+    if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
+#include "nbody_forces_v3.inc"
+#undef NB_V3_REAL
 #undef NB_V3_SIGNATURE
 #undef NB_V3_LDS
 #undef NB_V3_LANE
@@ -382,6 +483,7 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
 // for the ComputeForces<<<>>> site when it is launched with the reference's own block count
 // (src/nbody.cu:473,481-482).  Velocities are updated in place (:264), updatedMasses / updatedRadii written
 // (:245-246), positions are left to MoveBodies, bodies without a thread in the reference are not touched.
+#define NB_V3_REAL float
 #define NB_V3_SIGNATURE                                                                                      \
     __global__ __launch_bounds__(2 * kTile, 4) void ref_layout_forces_v3_f32(                                \
         void* bodyData, float* __restrict__ updM, float* __restrict__ updR, const int N, StepParams<float> p)
@@ -413,6 +515,7 @@ __device__ __forceinline__ float dpp_row_shl(float v) {
 #define NB_V3_KEEP(q, i, a, v) (void)q;
 #define NB_V3_COUNT(pairs) (void)pairs;
 #include "nbody_forces_v3.inc"
+#undef NB_V3_REAL
 #undef NB_V3_SIGNATURE
 #undef NB_V3_LDS
 #undef NB_V3_LANE
@@ -955,6 +1058,40 @@ __global__ __launch_bounds__(256) void selftest_ieee_f32(unsigned long long* mis
     if (bad_sqrt) atomicAdd(&mism[0], bad_sqrt);
     if (bad_rcp) atomicAdd(&mism[1], bad_rcp);
     if (bad_fast) atomicAdd(&mism[2], bad_fast);
+}
+
+// Device self-test of the fp64 fast chain against the compiler's IEEE sqrt and 1/x on its guarded domain: per
+// thread `iters` inputs from a counter-based generator.  mode 0: random mantissa, exponent uniform in [-500, 500];
+// mode 1: mantissas within 2^12 ulps of a power of two from either side; mode 2: perfect squares +- 4 ulps.
+__global__ __launch_bounds__(256) void selftest_chain_f64(unsigned long long* mism, int mode, int iters,
+                                                          unsigned long long seed) {
+    unsigned long long s = seed + 0x1234567ull * ((unsigned long long)blockIdx.x * 256 + threadIdx.x);
+    auto next = [&]() {
+        unsigned long long z = (s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+    };
+    unsigned long long bad_sqrt = 0, bad_inv = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned long long r = next(), r2 = next();
+        const int e = (int)(r2 % 1001) - 500;
+        unsigned long long man = r & 0xfffffffffffffull;
+        if (mode == 1) man = (r & 1) ? ((r >> 1) & 0xfff) : 0xfffffffffffffull - ((r >> 1) & 0xfff);
+        double x = __longlong_as_double((long long)(((unsigned long long)(e + 1023) << 52) | man));
+        if (mode == 2) {
+            const double k = (double)((r >> 20) | 1);
+            x = __longlong_as_double(__double_as_longlong(k * k) + (long long)(r2 % 9) - 4);
+        }
+        const FastChainD f = fast_chain(x);
+        const double d = ieee_sqrt<double>(x);
+        const double c = (d * d) * d;
+        const double inv = 1.0 / c;
+        bad_sqrt += __double_as_longlong(f.d) != __double_as_longlong(d);
+        bad_inv += __double_as_longlong(f.inv) != __double_as_longlong(inv);
+    }
+    if (bad_sqrt) atomicAdd(&mism[0], bad_sqrt);
+    if (bad_inv) atomicAdd(&mism[1], bad_inv);
 }
 
 }  // namespace nbk

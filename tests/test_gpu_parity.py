@@ -42,6 +42,14 @@ def test_ieee_sqrt_and_reciprocal_exhaustive(nb):
     assert (m[0], m[1], m[2]) == (0, 0, 0)
 
 
+def test_fp64_fast_chain_against_ieee(nb):
+    """2^32 inputs of each of three families of the guarded domain: the fp64 force kernel's sqrt / 1/d^3 chain
+    gives the bits of the compiler's correctly-rounded sqrt and divide (not exhaustive: fp64 cannot be)."""
+    m = (ctypes.c_uint64 * 2)()
+    assert nb.lib.nbody_selftest_chain_f64(0, 1 << 32, ctypes.byref(m)) == 0, nb.lib.nbody_last_error_string()
+    assert (m[0], m[1]) == (0, 0)
+
+
 def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
     return nb.Stepper(capacity=cap, timestep=float(dt), growthRate=float(growth), fieldWidth=fw, fieldHeight=fh,
                       **kw)
@@ -697,19 +705,57 @@ def test_error_paths(nb):
     st.close(); st2.close()
 
 
-def test_fp64_matches_oracle(nb):
-    """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); the HIP path is
-    checked bit-exactly against the fp64 instantiation of the oracle."""
-    cfg = nb.stock_config(particleCount=1500, fieldWidth=6000, fieldHeight=6000)
+@pytest.mark.parametrize("variant", [0, 1], ids=["production-kernel", "general-kernel"])
+@pytest.mark.parametrize("n,field,max_r", [(1500, 6000, 200.0), (4096, 100000, 200.0), (5000, 100000, 0.0)])
+def test_fp64_matches_oracle(nb, n, field, max_r, variant):
+    """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); both fp64 kernels
+    (fast chain / compiler IEEE sqrt and divide) are checked bit-exactly against the fp64 instantiation of the
+    oracle, with events, dense and sparse, with and without radii."""
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=0.0, maxRadius=max_r)
     bodies = nb.init_bodies(cfg, nb.F64)
-    st = nb.Stepper(cfg, precision=nb.F64)
+    st = nb.Stepper(cfg, precision=nb.F64, kernel_variant=variant, record_events=True)
     st.upload(bodies)
     blk = bodies.contiguousData.copy()
-    n = 1500
-    for s in range(6):
+    cur = n
+    for s in range(4):
         st.step(1)
-        n, *_ = ol.port_step(blk, n, float(DT), 6000, 6000, float(GROWTH), want_events=False)
+        cur, stats, ab, de, _ = ol.port_step(blk, cur, float(DT), field, field, float(GROWTH))
+        ev = st.events()
+        ev = ev[ev["step"] == s]
+        assert sorted((int(e["i"]), int(e["j"])) for e in ev[ev["kind"] == 0]) == \
+            sorted((int(a), int(b)) for a, b in ab), "E_t step %d" % s
         out = st.download()
-        assert out.numBodies == n
-        assert np.array_equal(bits(out.block), bits(blk[:6 * n])), "fp64 step %d" % s
+        assert out.numBodies == cur
+        assert np.array_equal(bits(out.block), bits(blk[:6 * cur])), "fp64 step %d" % s
     st.close()
+
+
+def test_fp64_extreme_values(nb):
+    """fp64 bodies outside the fast chain's domain (huge / non-finite / coincident / denormally close): the
+    per-tile coordinate bound and the per-pair flag must hand them to the general code."""
+    n = 1024
+    cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg, nb.F64)
+    P, M = bodies.Positions, bodies.Masses
+    P[100] = [1e200, -3e250]           # beyond the 2^249 coordinate bound
+    P[300] = [np.inf, 5.0]
+    P[301] = [np.nan, 7.0]
+    P[500] = P[499]                    # coincident: d2 == 0 <= 0 -> collision
+    P[700] = [3e-200, 1e-201]
+    P[701] = [3e-200 + 1e-215, 1e-201]  # d2 far below 2^-500
+    P[900] = [1.0e-3, 0]
+    P[901] = [1.0e-3 + 2.0e-19, 0]
+    M[600] = np.inf
+    M[601] = np.nan
+    for variant in (0, 1):
+        st = nb.Stepper(cfg, precision=nb.F64, kernel_variant=variant)
+        st.upload(bodies)
+        st.step(2)
+        out = st.download()
+        blk = bodies.contiguousData.copy()
+        cur = n
+        for s in range(2):
+            cur, *_ = ol.port_step(blk, cur, float(DT), 100000, 100000, float(GROWTH), want_events=False)
+        assert out.numBodies == cur
+        assert _nan_aware_equal(out.block, blk[:6 * cur]), "variant %d" % variant
+        st.close()
