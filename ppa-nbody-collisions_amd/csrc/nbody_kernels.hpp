@@ -322,9 +322,12 @@ __device__ __forceinline__ bool not_plus_zero(float x) { return __float_as_uint(
 __device__ __forceinline__ bool not_plus_zero(double x) { return __double_as_longlong(x) != 0ll; }
 
 // ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "v3" (fp32): the production kernel.
+// Force + collision + drift kernel, variant "v3": the production kernel.  Its text lives in nbody_forces_v3.inc
+// and is instantiated below for: fp32 with 128-thread workgroups and K lanes per body (forces_v3_f32), fp32 and
+// fp64 with 256-thread workgroups (forces_v3w_f32 / forces_v3w_f64, the defaults), and the reference's device
+// block layout (ref_layout_forces_v3_f32).
 //
-//   * 128-lane workgroup = 128/K bodies of one reference block, K consecutive lanes per body.  Lane h of a
+//   * 128-lane group = 128/K bodies of one reference block, K consecutive lanes per body.  Lane h of a
 //     group evaluates the tile entries off = h, h+K, h+2K, ... of the body's walk; the running force sum
 //     lives in lane h = 0 and takes the K terms of a round strictly in walk order (own term, then the
 //     neighbours' through DPP row_shl), so the fp32 accumulation order - and therefore every bit of the
