@@ -97,6 +97,17 @@ def parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR):
             "bitwise_equal": bitwise}
 
 
+def baseline_config_name(a):
+    """Which entry of BASELINE.json's `configs` the workload has the shape of (the metric is quoted on [3])."""
+    if a.fp64:
+        return "BASELINE.json configs[4] shape: " if a.bodies == 1048576 and not a.stock_radii else ""
+    if a.bodies == 262144 and not a.stock_radii:
+        return "BASELINE.json configs[3] (the metric's configuration): "
+    if a.bodies == 65536:
+        return "BASELINE.json configs[2] shape: " if a.stock_radii else "BASELINE.json configs[1] shape: "
+    return ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,9 +215,9 @@ def main():
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64" if a.fp64 else "f32",
             "data": "synthetic",
-            "config": {"workload": "N=%d bodies, %s, %s, reference initial condition (seed 1024), literal "
+            "config": {"workload": "%sN=%d bodies, %s, %s, reference initial condition (seed 1024), literal "
                                    "reference step semantics, %d steps" %
-                                   (a.bodies, "fp64" if a.fp64 else "fp32",
+                                   (baseline_config_name(a), a.bodies, "fp64" if a.fp64 else "fp32",
                                     "stock radii 50-200 (collisions on)" if a.stock_radii else "radii 0",
                                     a.steps),
                        "bodies_after": s1.n_bodies,
