@@ -302,6 +302,45 @@ __device__ __forceinline__ FastChainD fast_chain(double x) {
     return FastChainD{d, __builtin_fma(e2, q2, q2)};
 }
 
+// Two chains at once on 2-vectors, element-wise (the same operations per element as fast_chain, hence the same
+// bits): on gfx950 the fp32 multiplies and fmas become v_pk_mul_f32 / v_pk_fma_f32, one instruction for both
+// pairs.  Same-box, bare sequence (csrc/tune/pair_probe.hip): +14 % pairs/s at 4 waves per SIMD, +19 % at 1.
+template <typename T> struct Pair;
+template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Pair<double> { typedef double type __attribute__((ext_vector_type(2))); };
+__device__ __forceinline__ Pair<float>::type fast_inv_cube2(Pair<float>::type d2) {
+    typedef Pair<float>::type V;
+    V y;
+    y.x = __builtin_amdgcn_rsqf(d2.x);
+    y.y = __builtin_amdgcn_rsqf(d2.y);
+    const V g = d2 * y;
+    const V h = y * 0.5f;
+    const V e = __builtin_elementwise_fma(-g, g, d2);
+    const V d = __builtin_elementwise_fma(e, h, g);
+    const V c = (d * d) * d;
+    V r;
+    r.x = __builtin_amdgcn_rcpf(c.x);
+    r.y = __builtin_amdgcn_rcpf(c.y);
+    const V one = {1.0f, 1.0f};
+    const V e2 = __builtin_elementwise_fma(-c, r, one);
+    return __builtin_elementwise_fma(e2, r, r);
+}
+__device__ __forceinline__ Pair<double>::type fast_inv_cube2(Pair<double>::type d2) {
+    Pair<double>::type inv;                                // no packed fp64 instructions: two scalar chains
+    inv.x = fast_chain(d2.x).inv;
+    inv.y = fast_chain(d2.y).inv;
+    return inv;
+}
+
+// a + b as an instruction the SLP vectoriser cannot see: left alone it merges the two pairs' (dx^2 + dy^2) adds into
+// one v_pk_add_f32 and pays for it with three v_mov_b32 that gather the operands
+__device__ __forceinline__ float add_unmerged(float a, float b) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double add_unmerged(double a, double b) { return a + b; }
+
 // the guarded domain of the fast chains per precision: pairs with d2 <= fma(rs, rs, lo) or a coordinate at or beyond
 // `coord` (so d2 could exceed the upper edge) are left to the general code
 template <typename T> struct FastDomain;
@@ -394,10 +433,9 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 // The same kernel with 256-thread workgroups: two independent 128-lane groups (each one reference block or a
 // K-th of it, each with its own tiles) share a workgroup and its barriers, so that a workgroup has four waves and
 // the dispatcher puts one on every SIMD (two 2-wave workgroups per CU land 2-1-1-0,
-// profiles/r01_wave_placement.txt), and 16 instead of 8 tile reads are in flight per batch.  kOcc = waves per SIMD
-// the register budget is sized for: 4 (118 VGPRs) when the own range fills the chip, 2 (130 VGPRs) below.
-// Same-box A/B at N=262144 against the 128-thread kernel: 37.95 vs 38.92 ms (1 rank), 21.3 vs 22.5 ms per rank
-// (2 ranks).  This is the one-lane-per-body production kernel.
+// profiles/r01_wave_placement.txt).  kOcc = waves per SIMD the register budget is sized for: 4 (8 tile reads per
+// batch, 96 VGPRs) when the own range fills the chip, 2 (16 reads per batch) below.  This is the one-lane-per-body
+// production kernel: 33.5 ms per step at N=262144 on one GPU.
 #define NB_V3_REAL float
 #define NB_V3_SIGNATURE                                                                                      \
     template <int K, bool kLog, int kOcc>                                                                    \
@@ -414,7 +452,7 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
     int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
 #define NB_V3_LANE const int lane = threadIdx.x % kTile;
 #define NB_V3_WG const int wg = blockIdx.x * 2 + threadIdx.x / kTile;
-#define NB_V3_BATCH 16
+#define NB_V3_BATCH (kOcc >= 4 ? 8 : 16)
 #define NB_V3_CONSTANTS
 #define NB_V3_RANGE const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
 #define NB_V3_REC(j) J[j]
@@ -499,7 +537,7 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
     int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
 #define NB_V3_LANE const int lane = threadIdx.x % kTile;
 #define NB_V3_WG const int wg = blockIdx.x * 2 + threadIdx.x / kTile;
-#define NB_V3_BATCH 16
+#define NB_V3_BATCH 8
 #define NB_V3_CONSTANTS                                                                                      \
     constexpr int K = 1;                                                                                     \
     constexpr bool kLog = false;
@@ -1056,6 +1094,13 @@ __global__ __launch_bounds__(256) void selftest_ieee_f32(unsigned long long* mis
             const float c = (s1 * s1) * s1;
             const float inv = 1.0f / c;
             bad_fast += (__float_as_uint(f.d) != __float_as_uint(s1)) || (__float_as_uint(f.inv) != __float_as_uint(inv));
+            // the 2-vector form, with this input in either element
+            Pair<float>::type v2;
+            v2.x = x; v2.y = 3.0f;
+            const Pair<float>::type i2 = fast_inv_cube2(v2);
+            v2.x = 0.75f; v2.y = x;
+            const Pair<float>::type j2 = fast_inv_cube2(v2);
+            bad_fast += (__float_as_uint(i2.x) != __float_as_uint(inv)) || (__float_as_uint(j2.y) != __float_as_uint(inv));
         }
     }
     if (bad_sqrt) atomicAdd(&mism[0], bad_sqrt);

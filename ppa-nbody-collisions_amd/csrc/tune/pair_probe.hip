@@ -44,6 +44,27 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out
                 F.x = F.x + inv * (m * dx);
                 F.y = F.y + inv * (m * dy);
                 (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
+            } else if (MODE == 2) {   // two pairs at a time: (x,y) packed within a pair, the d2 -> inv chain packed ACROSS the pairs
+                if (u & 1) continue;
+                float2_ recb = rec; recb.x += 0.37f;
+                asm volatile("" : "+v"(rec), "+v"(recb), "+v"(m));
+                const float2_ da = rec - pi, db = recb - pi;
+                const float2_ sa = da * da, sb = db * db;
+                float2_ q2; q2.x = sa.x + sa.y; q2.y = sb.x + sb.y;
+                flagacc |= __builtin_amdgcn_fcmpf(q2.x, lo, 5);
+                flagacc |= __builtin_amdgcn_fcmpf(q2.y, lo, 5);
+                float2_ yy; yy.x = __builtin_amdgcn_rsqf(q2.x); yy.y = __builtin_amdgcn_rsqf(q2.y);
+                const float2_ gg = q2 * yy, hh = yy * 0.5f;
+                const float2_ ee = __builtin_elementwise_fma(-gg, gg, q2);
+                const float2_ ds = __builtin_elementwise_fma(ee, hh, gg);
+                const float2_ cc = (ds * ds) * ds;
+                float2_ rr; rr.x = __builtin_amdgcn_rcpf(cc.x); rr.y = __builtin_amdgcn_rcpf(cc.y);
+                const float2_ one = {1.0f, 1.0f};
+                const float2_ e2 = __builtin_elementwise_fma(-cc, rr, one);
+                const float2_ inv = __builtin_elementwise_fma(e2, rr, rr);
+                F = F + (da * m) * inv.x;
+                F = F + (db * m) * inv.y;
+                (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
             } else {           // same work with scalar (non-packed) ops only: 22 VALU
                 float dx, dy, a2, b2, mx, my, tx, ty;
                 asm volatile(
@@ -110,5 +131,6 @@ int main() {
     CK(hipMalloc((void**)&d_cyc, 8 * 8192)); CK(hipMalloc((void**)&d_out, 64));
     run<0>("packed, serial chain", d_cyc, d_out);
     run<1>("scalar ops only", d_cyc, d_out);
+    run<2>("chain packed across 2", d_cyc, d_out);
     return 0;
 }
