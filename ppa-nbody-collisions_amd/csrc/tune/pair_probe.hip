@@ -19,6 +19,7 @@ typedef float float2_ __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out, int trips) {
     float2_ rec = {1.0f + threadIdx.x * 0.001f, 2.0f}, pi = {0.5f, 0.25f}, F = {0.f, 0.f};
+    float2_ recb = {1.37f + threadIdx.x * 0.001f, 2.0f};
     float m = 3.0f;
     const float lo = 0x1p-80f;
     unsigned long long flagacc = 0;
@@ -46,11 +47,12 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out
                 (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
             } else if (MODE == 2) {   // two pairs at a time: (x,y) packed within a pair, the d2 -> inv chain packed ACROSS the pairs
                 if (u & 1) continue;
-                float2_ recb = rec; recb.x += 0.37f;
                 asm volatile("" : "+v"(rec), "+v"(recb), "+v"(m));
                 const float2_ da = rec - pi, db = recb - pi;
                 const float2_ sa = da * da, sb = db * db;
-                float2_ q2; q2.x = sa.x + sa.y; q2.y = sb.x + sb.y;
+                float2_ q2;
+                asm("v_add_f32 %0, %1, %2" : "=v"(q2.x) : "v"(sa.x), "v"(sa.y));   // as add_unmerged() in the kernel
+                asm("v_add_f32 %0, %1, %2" : "=v"(q2.y) : "v"(sb.x), "v"(sb.y));
                 flagacc |= __builtin_amdgcn_fcmpf(q2.x, lo, 5);
                 flagacc |= __builtin_amdgcn_fcmpf(q2.y, lo, 5);
                 float2_ yy; yy.x = __builtin_amdgcn_rsqf(q2.x); yy.y = __builtin_amdgcn_rsqf(q2.y);
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out
                     : "vcc", "s10", "s11");
             }
             rec.x += 1e-3f;
+            if (MODE == 2) recb.x += 1e-3f;
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
