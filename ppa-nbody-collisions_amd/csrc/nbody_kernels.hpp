@@ -689,6 +689,28 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
         tx = ch.inv * (bj.m * dx);
         ty = ch.inv * (bj.m * dy);
     };
+    // two walk positions at once on 2-vectors, as in the one-lane kernel (nbody_forces_v3.inc)
+    auto term2 = [&](const Rec<T>& ba, const Rec<T>& bb, unsigned long long& flag, Vec2<T>& ta, Vec2<T>& tb) {
+        typedef Pair<float>::type V2;
+        V2 own, pa, pb;
+        own.x = a.xi; own.y = a.yi;
+        pa.x = ba.x; pa.y = ba.y;
+        pb.x = bb.x; pb.y = bb.y;
+        const V2 da = pa - own, db = pb - own;
+        const V2 sa = da * da, sb = db * db;
+        V2 d2, q, rs;
+        d2.x = add_unmerged(sa.x, sa.y);
+        d2.y = add_unmerged(sb.x, sb.y);
+        rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
+        q.x = kFastLo; q.y = kFastLo;
+        q = __builtin_elementwise_fma(rs, rs, q);                              // flag only
+        flag |= le_mask(d2.x, q.x);
+        flag |= le_mask(d2.y, q.y);
+        const V2 inv = fast_inv_cube2(d2);
+        const V2 va = (da * ba.m) * inv.x, vb = (db * bb.m) * inv.y;
+        ta = Vec2<T>{va.x, va.y};
+        tb = Vec2<T>{vb.x, vb.y};
+    };
     // chain-lane general code on walk positions [o0, o1) of tile kk (buffer kk & 1, first body st)
     auto general = [&](int kk, long long st, int o0, int o1) {
         const int L = tile_len(kk, st);
@@ -793,10 +815,17 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
                     for (int r = 0; r < kPer; ++r) rec[r] = walk[r];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int r = 0; r < kPer; ++r) {
+                    for (int r = 0; r + 1 < kPer; r += 2) {
+                        Vec2<T> ta, tb;
+                        term2(rec[r], rec[r + 1], flag, ta, tb);
+                        terms[buf][(pw * kPer + r) / 2][l].p[(pw * kPer + r) & 1] = ta;
+                        terms[buf][(pw * kPer + r + 1) / 2][l].p[(pw * kPer + r + 1) & 1] = tb;
+                    }
+                    static_assert(kPer % 2 == 1, "the last position of a producer is evaluated alone");
+                    {
                         float tx, ty;
-                        term(rec[r], flag, tx, ty);
-                        terms[buf][(pw * kPer + r) / 2][l].p[(pw * kPer + r) & 1] = Vec2<T>{tx, ty};
+                        term(rec[kPer - 1], flag, tx, ty);
+                        terms[buf][(pw * kPer + kPer - 1) / 2][l].p[(pw * kPer + kPer - 1) & 1] = Vec2<T>{tx, ty};
                     }
                     if (l == 0) flagmask[buf][pw] = flag;
                 } else if (pending) {
