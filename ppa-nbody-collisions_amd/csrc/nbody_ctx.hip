@@ -228,12 +228,13 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
     // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144, profiles/r01_scaling_probe_*.txt):
-    //   >= 200k bodies : one lane per body, 256-thread workgroups, 4 waves per SIMD
-    //   >= 60k bodies  : the same with the register budget of 2 waves per SIMD (one wave per SIMD at 64k bodies:
-    //                    12.4 ms per launch against the 2048 tiles of N=262144, producer/consumer 13.9 ms)
+    //   >= 100k bodies : one lane per body, 256-thread workgroups, registers sized for 4 waves per SIMD
+    //   >= 60k bodies  : the same with the register budget of 2 waves per SIMD and 16 reads per batch (one wave
+    //                    per SIMD at 64k bodies: 11.6 ms per launch against the 2048 tiles of N=262144,
+    //                    producer/consumer 12.3 ms)
     //   below          : 8-wave producer/consumer workgroups per 64 bodies (its time shrinks with the own range,
     //                    the one-lane kernel's does not once there is less than a wave per SIMD)
-    if (c->own_upper >= 200000) launch_v3w<1, 4>(c, p, nblocks, log);
+    if (c->own_upper >= 100000) launch_v3w<1, 4>(c, p, nblocks, log);
     else if (c->own_upper >= 61440) launch_v3w<1, 2>(c, p, nblocks, log);
     else launch_pc8(c, p, nblocks, log);
 }
