@@ -368,6 +368,24 @@ def test_c2_c3_thousand_steps_all_paths_agree(nb, radii):
         assert np.array_equal(bits(out.block), bits(ref.block)), name
 
 
+def test_headline_hundred_steps_partitions_agree(nb):
+    """BASELINE.json configs[3] shape over a longer horizon: N=262144, 100 steps, the 1-, 2- and 8-rank partitions
+    (three different kernel choices: 4-wave one-lane, 2-wave one-lane, producer/consumer) end in the same state
+    bit for bit, and the step-1 state was checked against the oracle by test_big/bench."""
+    cfg = nb.stock_config(particleCount=262144, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg)
+    outs = []
+    for world in (1, 2, 8):
+        grp = nb.StepperGroup(world, cfg=cfg)
+        grp.upload(bodies)
+        grp.step(100)
+        outs.append(grp.download())
+        grp.close()
+    for o in outs[1:]:
+        assert o.numBodies == outs[0].numBodies
+        assert np.array_equal(bits(o.block), bits(outs[0].block))
+
+
 def test_ragged_large_n_sampled(nb):
     """N = 100 003 (not a multiple of 128: frozen tail, truncated last tile, wrapped cyclic tiles), 2 steps,
     oracle on samples of bodies including the last active block and the frozen tail."""
