@@ -152,8 +152,8 @@ typedef struct nbody_ctx_desc {
     const void* comm_id;    /* world>1 with RCCL: 128-byte id from nbody_comm_unique_id on rank 0       */
     int kernel_variant;     /* 0 = automatic (by own-range size); tuning / A-B testing only: 1 general kernel, */
                             /* 11/12/14/18 one-lane..eight-lanes-per-body kernel, 31/32 its 256-thread form,   */
-                            /* 40 producer/consumer kernel.  fp64: 1 selects the general kernel, anything else  */
-                            /* the fp64 production kernel                                                       */
+                            /* 40 producer/consumer kernel, 50 ring-of-waves kernel.  fp64: 1 selects the       */
+                            /* general kernel, anything else the fp64 production kernel                         */
 } nbody_ctx_desc;
 
 void nbody_ctx_desc_from_config(nbody_ctx_desc* d, const nbody_config* cfg, int precision);

@@ -170,7 +170,7 @@ int read_meta(nbody_ctx* c) {
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
 //                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body, 128-thread workgroups |
 //                 31,32 v3 K = 1 with 256-thread workgroups, registers sized for 4 / 2 waves per SIMD |
-//                 40 pc8 (producer/consumer)
+//                 40 pc8 (producer/consumer) | 50 ring of waves
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -210,6 +210,12 @@ inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bo
     else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
+inline void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+}
+
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     switch (c->desc.kernel_variant) {
@@ -224,18 +230,16 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
         case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
         case 40: launch_pc8(c, p, nblocks, log); return;
+        case 50: launch_ring(c, p, nblocks, log); return;
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
-    // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144, profiles/r01_scaling_probe_*.txt):
+    // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144 and bench.py at smaller N, profiles/):
     //   >= 100k bodies : one lane per body, 256-thread workgroups, registers sized for 4 waves per SIMD
-    //   >= 60k bodies  : the same with the register budget of 2 waves per SIMD and 16 reads per batch (one wave
-    //                    per SIMD at 64k bodies: 11.6 ms per launch against the 2048 tiles of N=262144,
-    //                    producer/consumer 12.3 ms)
-    //   below          : 8-wave producer/consumer workgroups per 64 bodies (its time shrinks with the own range,
-    //                    the one-lane kernel's does not once there is less than a wave per SIMD)
+    //   >= 8k bodies   : ring of 8 waves per 64 bodies (11.6 vs 12.5 ms at 64k own bodies, 6.4 vs 7.1 ms at 32k)
+    //   below          : 8-wave producer/consumer workgroups per 64 bodies
     if (c->own_upper >= 100000) launch_v3w<1, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 61440) launch_v3w<1, 2>(c, p, nblocks, log);
+    else if (c->own_upper >= 8192) launch_ring(c, p, nblocks, log);
     else launch_pc8(c, p, nblocks, log);
 }
 

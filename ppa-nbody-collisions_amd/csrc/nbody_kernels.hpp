@@ -341,6 +341,12 @@ __device__ __forceinline__ float add_unmerged(float a, float b) {
 }
 __device__ __forceinline__ double add_unmerged(double a, double b) { return a + b; }
 
+// Orders this wave's LDS accesses (and keeps the compiler from moving memory accesses across) WITHOUT waiting for
+// outstanding global loads: a workgroup-scope fence or __syncthreads() emits s_waitcnt vmcnt(0), which puts the
+// latency of a prefetch from the replica (a microsecond or two) on the critical path of whoever waits.
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // the guarded domain of the fast chains per precision: pairs with d2 <= fma(rs, rs, lo) or a coordinate at or beyond
 // `coord` (so d2 could exceed the upper edge) are left to the general code
 template <typename T> struct FastDomain;
@@ -876,6 +882,268 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
         for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
         if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Force + collision + drift kernel, variant "ring" (fp32): for own ranges with fewer chains than the chip has lanes.
+//
+// A workgroup of 8 waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
+// turns of 32 positions and the turns go round the waves: wave w takes turns w, w + 8, w + 16, ...  For its turn a
+// wave (1) loads the 95 tile entries its lanes need straight from the replica into a private LDS window (prefetched
+// one turn of its own ahead), (2) evaluates the 32 terms of every lane into registers - this is 14 of the 15
+// instructions per pair and depends on nothing -, (3) waits until the running state {fx, fy, mnew, rnew, deleted}
+// after the previous turn has been published in LDS by the wave before it, (4) adds its 32 terms to it in walk order
+// (or, for a flagged lane / a special tile, runs the general code on the 32 positions), and (5) publishes the
+// state for the next wave.  So the ordered chain of every body passes through all eight waves in turn, each holding it
+// only for 32 adds, while the other seven evaluate terms: no wave is a dedicated (half idle) chain wave, no term
+// goes through LDS, there is no workgroup barrier in the loop, and the instruction count per pair is that of the
+// one-lane kernel.  The hand-off is a sequence number in LDS that the next wave polls; LDS operations of a wave
+// execute in order, so the state is visible before the number.  Every wave leaves after its last turn.
+// First / last tile of a walk (self skip, truncation), the clean semantics' own tile and windows with unbounded
+// coordinates are done by the general code with records fetched from the replica.
+// ---------------------------------------------------------------------------------------------------------
+template <bool kLog>
+__global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
+                     Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
+                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
+    typedef float T;
+    typedef Pair<float>::type V2;
+    constexpr int kW = 8;                                  // waves in the ring
+    constexpr int kT = 32;                                 // walk positions per turn
+    constexpr int kTurnsPerTile = kTile / kT;
+    constexpr int kWin = kWave + kT;                       // window entries a turn can touch (95 used)
+    __shared__ Rec<T> win[kW][2][kWin];                    // per wave, double buffered
+    struct alignas(8) HandF { float fx, fy; };             // state after a turn, two LDS accesses per lane
+    struct alignas(16) HandM { float mnew, rnew; int deleted, pad; };
+    __shared__ HandF hand_f[2][kWave];
+    __shared__ HandM hand_m[2][kWave];
+    __shared__ int seq;                                    // number of turns whose state has been published
+    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    const int tid = threadIdx.x;
+    const int w = tid / kWave;
+    const int l = tid % kWave;
+    const int wg = blockIdx.x;
+    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
+    const int t0 = (wg % 2) * kWave;
+    const int t = t0 + l;                                  // threadIdx.x of this lane's body in the reference
+    const long long blk0 = (long long)b * kTile;
+    if (blk0 + t0 >= (long long)lo + cnt) return;
+    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
+    const bool lit = p.literal != 0;
+    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
+    const int nturns = ntiles * kTurnsPerTile;
+
+    const long long i64 = blk0 + t;
+    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
+    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
+    BodyAcc<T> a;
+    if (mine) {
+        const Rec<T> me = J[i];
+        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
+    } else {
+        a.xi = a.yi = a.mi = a.ri = 0;
+    }
+    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
+    const bool lane_ok = !active || ((abs_(a.xi) < kCoordBound) && (abs_(a.yi) < kCoordBound));
+    const bool wave_ok = __ballot(!lane_ok) == 0ull;
+    unsigned long long pairs = 0;
+    if (tid == 0) seq = 0;
+    __syncthreads();                                       // the only workgroup barrier: seq is initialised
+
+    // First body of the tile of this wave's current turn (literal: cyclic tile b + kk), kept incrementally: a wave
+    // moves on by kW turns = two tiles at a time, and a division here would cost as much as the turn's arithmetic.
+    auto tile_start_slow = [&](int kk) -> long long {
+        if (!lit) return (long long)kk * kTile;
+        return (blk0 % N + (long long)kk * kTile) % N;
+    };
+    auto two_tiles_on = [&](long long st) -> long long {
+        st += 2 * kTile;
+        if (lit) {                                         // a next tile exists only when N >= 256: two wraps suffice
+            if (st >= N) st -= N;
+            if (st >= N) st -= N;
+        }
+        return st;
+    };
+    auto tile_len = [&](int kk, long long st) -> int {
+        if (lit) return (kk == nb - 1) ? N % (kTile + 1) : kTile;             // :194 (quirk Q1)
+        return (N - st) < kTile ? (int)(N - st) : kTile;
+    };
+    // is every position of tile kk an ordinary pair for every lane of the workgroup?
+    auto interior = [&](int kk, long long st) -> bool {
+        return lit ? (kk >= 1 && kk <= nb - 2) : (tile_len(kk, st) == kTile && kk != b);
+    };
+    // the window of a fast turn: entry j of the window is tile entry (wbase0 + off0 + j) mod 128
+    const int wbase0 = lit ? t0 : 0;                       // literal: lane l reads window[l + r]; clean: window[r]
+    const int nwin = lit ? (kWave + kT - 1) : kT;          // entries of the window that are used
+    auto window_body = [&](long long st, int off0, int j) -> int {
+        const int e = (wbase0 + off0 + j) & (kTile - 1);
+        long long src = st + e;
+        if (lit && src >= N) src -= N;                     // interior tiles only: N >= 384, one wrap
+        return (int)src;
+    };
+    // loads of the window of turn tau into registers (two entries per lane at most), to be stored by put_window
+    struct Fetched { Rec<T> r0, r1; bool fast; };
+    auto fetch = [&](int tau, long long st) -> Fetched {
+        Fetched f;
+        f.r0 = Rec<T>{0, 0, 0, 0};
+        f.r1 = f.r0;
+        f.fast = false;
+        if (tau >= nturns) return f;
+        const int kk = tau / kTurnsPerTile;
+        if (!(interior(kk, st) && wave_ok)) return f;
+        const int off0 = (tau % kTurnsPerTile) * kT;
+        if (l < nwin) f.r0 = J[window_body(st, off0, l)];
+        if (l + kWave < nwin) f.r1 = J[window_body(st, off0, l + kWave)];
+        const bool bad0 = l < nwin && !((abs_(f.r0.x) < kCoordBound) && (abs_(f.r0.y) < kCoordBound));
+        const bool bad1 = l + kWave < nwin && !((abs_(f.r1.x) < kCoordBound) && (abs_(f.r1.y) < kCoordBound));
+        f.fast = __ballot(bad0 || bad1) == 0ull;
+        return f;
+    };
+    auto put_window = [&](const Fetched& f, int buf) {
+        win[w][buf][l] = f.r0;
+        if (l < kT) win[w][buf][l + kWave] = f.r1;
+        __builtin_amdgcn_wave_barrier();                   // reads of the window come after these writes
+    };
+    // one walk position by the general code, record fetched from the replica
+    auto general_at = [&](int kk, long long st, int L, int off) {
+        int sidx;
+        long long j;
+        if (lit) {
+            if (kk == 0 && off == 0) return;                                   // :200-204
+            sidx = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L); // :207
+            j = st + sidx;
+            if (j >= N) j %= N;
+        } else {
+            j = st + off;
+            if (j == i64) return;
+        }
+        interact<T, kLog>(a, J[j], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+    };
+
+    long long st = tile_start_slow(w / kTurnsPerTile);
+    Fetched cur = fetch(w, st);
+    int buf = 0;
+    if (cur.fast) put_window(cur, buf);
+    for (int tau = w; tau < nturns; tau += kW) {
+        const int kk = tau / kTurnsPerTile;
+        const int off0 = (tau % kTurnsPerTile) * kT;
+        const int L = tile_len(kk, st);
+        const bool fast = cur.fast;
+        const long long st_next = two_tiles_on(st);
+        const Fetched nxt = fetch(tau + kW, st_next);      // in flight while this turn is evaluated
+        // (2) the 32 terms of this turn
+        V2 term[kT];
+        unsigned long long flag = 0;
+        if (fast) {
+            const Rec<T>* walk = &win[w][buf][lit ? l : 0];
+            V2 own;
+            own.x = a.xi; own.y = a.yi;
+#pragma unroll
+            for (int r0 = 0; r0 < kT; r0 += 4) {            // 4 reads per batch: the 32 terms already take 64 VGPRs
+                Rec<T> rec[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rec[u] = walk[r0 + u];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    const Rec<T> ba = rec[u], bb = rec[u + 1];
+                    V2 pa, pb;
+                    pa.x = ba.x; pa.y = ba.y;
+                    pb.x = bb.x; pb.y = bb.y;
+                    const V2 da = pa - own, db = pb - own;
+                    const V2 sa = da * da, sb = db * db;
+                    V2 d2, q, rs;
+                    d2.x = add_unmerged(sa.x, sa.y);
+                    d2.y = add_unmerged(sb.x, sb.y);
+                    rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
+                    q.x = kFastLo; q.y = kFastLo;
+                    q = __builtin_elementwise_fma(rs, rs, q);                  // flag only
+                    flag |= le_mask(d2.x, q.x);
+                    flag |= le_mask(d2.y, q.y);
+                    const V2 inv = fast_inv_cube2(d2);
+                    term[r0 + u] = (da * ba.m) * inv.x;
+                    term[r0 + u + 1] = (db * bb.m) * inv.y;
+                }
+            }
+        }
+        // (3) the state after turn tau - 1
+        if (tau > 0) {
+            int spins = 0;
+            while (*(volatile int*)&seq < tau) {
+                if (++spins > (1 << 26)) {                 // never seen; keeps a broken build from hanging the GPU
+                    if (l == 0) atomicAdd(&ctr->errors, 1ull);
+                    break;
+                }
+            }
+            asm volatile("" ::: "memory");                 // the state is read after the number (in-order LDS)
+            __builtin_amdgcn_s_setprio(3);                 // holding the chain: this wave's instructions go first
+            const int hp = tau & 1;
+            const HandF hf = hand_f[hp][l];
+            const HandM hm = hand_m[hp][l];
+            a.fx = hf.fx; a.fy = hf.fy;
+            a.mnew = hm.mnew; a.rnew = hm.rnew; a.deleted = hm.deleted;
+        }
+        // (4) this turn's positions, in walk order
+        if (fast) {
+            if (active) {
+                if ((flag >> l) & 1ull) {
+#pragma unroll 1
+                    for (int r = 0; r < kT; ++r) {
+                        const int off = off0 + r;
+                        const int sidx = lit ? ((t + off) & (kTile - 1)) : off;
+                        long long j = st + sidx;
+                        if (j >= N) j -= N;
+                        interact<T, kLog>(a, win[w][buf][(lit ? l : 0) + r], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+                    }
+                } else {
+                    V2 F;
+                    F.x = a.fx; F.y = a.fy;
+#pragma unroll
+                    for (int r = 0; r < kT; ++r) F = F + term[r];
+                    a.fx = F.x; a.fy = F.y;
+                }
+                pairs += kT;
+            }
+        } else if (active) {
+            const int hi = off0 + kT < L ? off0 + kT : L;
+            for (int off = off0; off < hi; ++off) general_at(kk, st, L, off);
+            if (lit) {
+                if (hi > off0) pairs += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
+            } else {
+                for (int off = off0; off < hi; ++off) pairs += (st + off != i64) ? 1 : 0;
+            }
+        }
+        // (5) publish the state, then the sequence number (LDS operations of a wave execute in order)
+        if (tau + 1 < nturns) {
+            const int hp = (tau + 1) & 1;
+            hand_f[hp][l] = HandF{a.fx, a.fy};
+            hand_m[hp][l] = HandM{a.mnew, a.rnew, a.deleted, 0};
+            asm volatile("" ::: "memory");                 // ... and written before it: a wave's LDS operations
+            if (l == 0) *(volatile int*)&seq = tau + 1;    // execute in order, no wait is needed in between
+            __builtin_amdgcn_s_setprio(0);
+        } else if (mine) {                                 // the last turn of the walk: epilogue by this wave
+            const int q = i - lo;
+            const Vec2<T> v = Vown[q];
+            if (active) {
+                Rec<T> out; Vec2<T> vout;
+                finish_body<T>(a, v, p, out, vout);
+                S_J[q] = out;
+                S_V[q] = vout;
+            } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
+                S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
+                S_V[q] = v;
+            }
+        }
+        // the prefetched window of this wave's next turn
+        buf ^= 1;
+        st = st_next;
+        cur = nxt;
+        if (cur.fast) put_window(cur, buf);
+    }
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
+    if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -55,7 +55,7 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40]   # automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8
+VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40, 50]   # automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8 | ring
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
