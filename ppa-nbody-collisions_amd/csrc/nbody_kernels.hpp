@@ -1032,7 +1032,6 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const int L = tile_len(kk, st);
         const bool fast = cur.fast;
         const long long st_next = two_tiles_on(st);
-        const Fetched nxt = fetch(tau + kW, st_next);      // in flight while this turn is evaluated
         // (2) the 32 terms of this turn
         V2 term[kT];
         unsigned long long flag = 0;
@@ -1068,6 +1067,9 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 }
             }
         }
+        // the window of this wave's next turn: in flight while it waits for and holds the chain (issued after the
+        // terms, so that its registers are not live during their evaluation)
+        const Fetched nxt = fetch(tau + kW, st_next);
         // (3) the state after turn tau - 1
         if (tau > 0) {
             int spins = 0;
