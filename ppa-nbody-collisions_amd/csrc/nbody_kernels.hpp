@@ -948,6 +948,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
     const bool lane_ok = !active || ((abs_(a.xi) < kCoordBound) && (abs_(a.yi) < kCoordBound));
     const bool wave_ok = __ballot(!lane_ok) == 0ull;
+    const bool wave_r0 = __ballot(active && not_plus_zero(a.ri)) == 0ull;
     unsigned long long pairs = 0;
     if (tid == 0) seq = 0;
     __syncthreads();                                       // the only workgroup barrier: seq is initialised
@@ -984,12 +985,13 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         return (int)src;
     };
     // loads of the window of turn tau into registers (two entries per lane at most), to be stored by put_window
-    struct Fetched { Rec<T> r0, r1; bool fast; };
+    struct Fetched { Rec<T> r0, r1; bool fast, rnz; };
     auto fetch = [&](int tau, long long st) -> Fetched {
         Fetched f;
         f.r0 = Rec<T>{0, 0, 0, 0};
         f.r1 = f.r0;
         f.fast = false;
+        f.rnz = true;
         if (tau >= nturns) return f;
         const int kk = tau / kTurnsPerTile;
         if (!(interior(kk, st) && wave_ok)) return f;
@@ -999,6 +1001,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const bool bad0 = l < nwin && !((abs_(f.r0.x) < kCoordBound) && (abs_(f.r0.y) < kCoordBound));
         const bool bad1 = l + kWave < nwin && !((abs_(f.r1.x) < kCoordBound) && (abs_(f.r1.y) < kCoordBound));
         f.fast = __ballot(bad0 || bad1) == 0ull;
+        // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
+        f.rnz = __ballot((l < nwin && not_plus_zero(f.r0.r)) || (l + kWave < nwin && not_plus_zero(f.r1.r))) != 0ull;
         return f;
     };
     auto put_window = [&](const Fetched& f, int buf) {
@@ -1039,33 +1043,42 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             const Rec<T>* walk = &win[w][buf][lit ? l : 0];
             V2 own;
             own.x = a.xi; own.y = a.yi;
+            auto evaluate = [&](auto r0_tag) {
+                constexpr bool kR0 = decltype(r0_tag)::value;
+                constexpr int kG = kR0 ? 8 : 4;            // reads per batch: the 32 terms already take 64 VGPRs
 #pragma unroll
-            for (int r0 = 0; r0 < kT; r0 += 4) {            // 4 reads per batch: the 32 terms already take 64 VGPRs
-                Rec<T> rec[4];
+                for (int r0 = 0; r0 < kT; r0 += kG) {
+                    Rec<T> rec[kG];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) rec[u] = walk[r0 + u];
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int u = 0; u < kG; ++u) rec[u] = walk[r0 + u];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; u += 2) {
-                    const Rec<T> ba = rec[u], bb = rec[u + 1];
-                    V2 pa, pb;
-                    pa.x = ba.x; pa.y = ba.y;
-                    pb.x = bb.x; pb.y = bb.y;
-                    const V2 da = pa - own, db = pb - own;
-                    const V2 sa = da * da, sb = db * db;
-                    V2 d2, q, rs;
-                    d2.x = add_unmerged(sa.x, sa.y);
-                    d2.y = add_unmerged(sb.x, sb.y);
-                    rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
-                    q.x = kFastLo; q.y = kFastLo;
-                    q = __builtin_elementwise_fma(rs, rs, q);                  // flag only
-                    flag |= le_mask(d2.x, q.x);
-                    flag |= le_mask(d2.y, q.y);
-                    const V2 inv = fast_inv_cube2(d2);
-                    term[r0 + u] = (da * ba.m) * inv.x;
-                    term[r0 + u + 1] = (db * bb.m) * inv.y;
+                    for (int u = 0; u < kG; u += 2) {
+                        const Rec<T> ba = rec[u], bb = rec[u + 1];
+                        V2 pa, pb;
+                        pa.x = ba.x; pa.y = ba.y;
+                        pb.x = bb.x; pb.y = bb.y;
+                        const V2 da = pa - own, db = pb - own;
+                        const V2 sa = da * da, sb = db * db;
+                        V2 d2, q;
+                        d2.x = add_unmerged(sa.x, sa.y);
+                        d2.y = add_unmerged(sb.x, sb.y);
+                        q.x = kFastLo; q.y = kFastLo;
+                        if (!kR0) {
+                            V2 rs;
+                            rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
+                            q = __builtin_elementwise_fma(rs, rs, q);          // flag only
+                        }
+                        flag |= le_mask(d2.x, q.x);
+                        flag |= le_mask(d2.y, q.y);
+                        const V2 inv = fast_inv_cube2(d2);
+                        term[r0 + u] = (da * ba.m) * inv.x;
+                        term[r0 + u + 1] = (db * bb.m) * inv.y;
+                    }
                 }
-            }
+            };
+            if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
+            else evaluate(std::false_type{});
         }
         // the window of this wave's next turn: in flight while it waits for and holds the chain (issued after the
         // terms, so that its registers are not live during their evaluation)
