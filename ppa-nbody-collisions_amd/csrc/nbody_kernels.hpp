@@ -889,8 +889,8 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
 //
 // A workgroup of 8 waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
 // turns of 32 positions and the turns go round the waves: wave w takes turns w, w + 8, w + 16, ...  For its turn a
-// wave (1) loads the 95 tile entries its lanes need straight from the replica into a private LDS window (prefetched
-// one turn of its own ahead), (2) evaluates the 32 terms of every lane into registers - this is 14 of the 15
+// wave (1) loads the 95 tile entries its lanes need straight from the replica into a private LDS window (direct-to-LDS
+// loads, prefetched one turn of its own ahead), (2) evaluates the 32 terms of every lane into registers - this is 14 of the 15
 // instructions per pair and depends on nothing -, (3) waits until the running state {fx, fy, mnew, rnew, deleted}
 // after the previous turn has been published in LDS by the wave before it, (4) adds its 32 terms to it in walk order
 // (or, for a flagged lane / a special tile, runs the general code on the 32 positions), and (5) publishes the
@@ -984,31 +984,39 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         if (lit && src >= N) src -= N;                     // interior tiles only: N >= 384, one wrap
         return (int)src;
     };
-    // loads of the window of turn tau into registers (two entries per lane at most), to be stored by put_window
-    struct Fetched { Rec<T> r0, r1; bool fast, rnz; };
-    auto fetch = [&](int tau, long long st) -> Fetched {
-        Fetched f;
-        f.r0 = Rec<T>{0, 0, 0, 0};
-        f.r1 = f.r0;
-        f.fast = false;
-        f.rnz = true;
-        if (tau >= nturns) return f;
+    // The window of turn tau, loaded from the replica STRAIGHT INTO LDS (global_load_lds_dwordx4: lane l's 16 bytes
+    // land at base + 16 l), so a prefetch holds no registers and can stay in flight for a whole turn.  Returns
+    // whether the turn can take the fast path as far as is known before the data has arrived.
+    auto issue_window = [&](int tau, long long st, int buf) -> bool {
+        if (tau >= nturns) return false;
         const int kk = tau / kTurnsPerTile;
-        if (!(interior(kk, st) && wave_ok)) return f;
+        if (!(interior(kk, st) && wave_ok)) return false;
         const int off0 = (tau % kTurnsPerTile) * kT;
-        if (l < nwin) f.r0 = J[window_body(st, off0, l)];
-        if (l + kWave < nwin) f.r1 = J[window_body(st, off0, l + kWave)];
-        const bool bad0 = l < nwin && !((abs_(f.r0.x) < kCoordBound) && (abs_(f.r0.y) < kCoordBound));
-        const bool bad1 = l + kWave < nwin && !((abs_(f.r1.x) < kCoordBound) && (abs_(f.r1.y) < kCoordBound));
-        f.fast = __ballot(bad0 || bad1) == 0ull;
-        // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
-        f.rnz = __ballot((l < nwin && not_plus_zero(f.r0.r)) || (l + kWave < nwin && not_plus_zero(f.r1.r))) != 0ull;
-        return f;
+        typedef const void __attribute__((address_space(1)))* GlobalPtr;
+        typedef void __attribute__((address_space(3)))* LdsPtr;
+        if (l < nwin)
+            __builtin_amdgcn_global_load_lds((GlobalPtr)(J + window_body(st, off0, l)), (LdsPtr)&win[w][buf][0], 16, 0, 0);
+        if (l + kWave < nwin)
+            __builtin_amdgcn_global_load_lds((GlobalPtr)(J + window_body(st, off0, l + kWave)),
+                                             (LdsPtr)&win[w][buf][kWave], 16, 0, 0);
+        return true;
     };
-    auto put_window = [&](const Fetched& f, int buf) {
-        win[w][buf][l] = f.r0;
-        if (l < kT) win[w][buf][l + kWave] = f.r1;
-        __builtin_amdgcn_wave_barrier();                   // reads of the window come after these writes
+    // after the loads have landed: are all coordinates of the window bounded, is some radius not +0.0f
+    struct WindowState { bool fast, rnz; };
+    auto check_window = [&](bool issued, int buf) -> WindowState {
+        if (!issued) return WindowState{false, true};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
+        if (l < nwin) r0 = win[w][buf][l];
+        if (l + kWave < nwin) r1 = win[w][buf][l + kWave];
+        const bool bad0 = !((abs_(r0.x) < kCoordBound) && (abs_(r0.y) < kCoordBound));
+        const bool bad1 = !((abs_(r1.x) < kCoordBound) && (abs_(r1.y) < kCoordBound));
+        WindowState ws;
+        ws.fast = __ballot(bad0 || bad1) == 0ull;
+        // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
+        ws.rnz = __ballot(not_plus_zero(r0.r) || not_plus_zero(r1.r)) != 0ull;
+        return ws;
     };
     // one walk position by the general code, record fetched from the replica
     auto general_at = [&](int kk, long long st, int L, int off) {
@@ -1027,15 +1035,15 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     };
 
     long long st = tile_start_slow(w / kTurnsPerTile);
-    Fetched cur = fetch(w, st);
     int buf = 0;
-    if (cur.fast) put_window(cur, buf);
+    WindowState cur = check_window(issue_window(w, st, buf), buf);
     for (int tau = w; tau < nturns; tau += kW) {
         const int kk = tau / kTurnsPerTile;
         const int off0 = (tau % kTurnsPerTile) * kT;
         const int L = tile_len(kk, st);
         const bool fast = cur.fast;
         const long long st_next = two_tiles_on(st);
+        const bool issued_next = issue_window(tau + kW, st_next, buf ^ 1);   // in flight for the whole turn
         // (2) the 32 terms of this turn
         V2 term[kT];
         unsigned long long flag = 0;
@@ -1080,9 +1088,6 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
             else evaluate(std::false_type{});
         }
-        // the window of this wave's next turn: in flight while it waits for and holds the chain (issued after the
-        // terms, so that its registers are not live during their evaluation)
-        const Fetched nxt = fetch(tau + kW, st_next);
         // (3) the state after turn tau - 1
         if (tau > 0) {
             int spins = 0;
@@ -1154,8 +1159,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         // the prefetched window of this wave's next turn
         buf ^= 1;
         st = st_next;
-        cur = nxt;
-        if (cur.fast) put_window(cur, buf);
+        cur = check_window(issued_next, buf);
     }
     for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
     if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
