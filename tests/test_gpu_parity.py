@@ -386,10 +386,11 @@ def test_headline_hundred_steps_partitions_agree(nb):
         assert np.array_equal(bits(o.block), bits(outs[0].block))
 
 
-def test_ragged_large_n_sampled(nb):
-    """N = 100 003 (not a multiple of 128: frozen tail, truncated last tile, wrapped cyclic tiles), 2 steps,
-    oracle on samples of bodies including the last active block and the frozen tail."""
-    n = 100003
+@pytest.mark.parametrize("n", [100003, 50003], ids=["one-lane-kernel", "ring-kernel"])
+def test_ragged_large_n_sampled(nb, n):
+    """N = 100 003 / 50 003 (not multiples of 128: frozen tail, truncated last tile, wrapped cyclic tiles; the
+    automatic kernel choice is the one-lane kernel for the first, the ring kernel for the second), one step,
+    oracle on samples of bodies including the last active block and the frozen tail, then the whole state."""
     cfg = nb.stock_config(particleCount=n, minRadius=5.0, maxRadius=20.0)
     bodies = nb.init_bodies(cfg)
     st = nb.Stepper(cfg)
@@ -411,7 +412,7 @@ def test_ragged_large_n_sampled(nb):
     # the whole state against the full oracle step (about 1e10 pairs on the host cores)
     ref = blk.copy()
     n1, *_ = ol.port_step(ref, n, DT, 100000, 100000, GROWTH, want_events=False)
-    assert_bodies_equal(out, ref, n1, "N=100003 step 1")
+    assert_bodies_equal(out, ref, n1, "N=%d step 1" % n)
     assert st.stats().pairs == ol.port().oracle_pairs_per_step(n, ol.LITERAL)
     st.close()
 
