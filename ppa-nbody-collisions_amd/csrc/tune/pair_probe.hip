@@ -67,6 +67,30 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out
                 F = F + (da * m) * inv.x;
                 F = F + (db * m) * inv.y;
                 (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
+            } else if (MODE == 3) {   // as MODE 2, reciprocal from the rsq seed: y^3, one Newton step, one correction (no v_rcp)
+                if (u & 1) continue;
+                asm volatile("" : "+v"(rec), "+v"(recb), "+v"(m));
+                const float2_ da = rec - pi, db = recb - pi;
+                const float2_ sa = da * da, sb = db * db;
+                float2_ q2;
+                asm("v_add_f32 %0, %1, %2" : "=v"(q2.x) : "v"(sa.x), "v"(sa.y));
+                asm("v_add_f32 %0, %1, %2" : "=v"(q2.y) : "v"(sb.x), "v"(sb.y));
+                flagacc |= __builtin_amdgcn_fcmpf(q2.x, lo, 5);
+                flagacc |= __builtin_amdgcn_fcmpf(q2.y, lo, 5);
+                float2_ yy; yy.x = __builtin_amdgcn_rsqf(q2.x); yy.y = __builtin_amdgcn_rsqf(q2.y);
+                const float2_ gg = q2 * yy, hh = yy * 0.5f;
+                const float2_ ee = __builtin_elementwise_fma(-gg, gg, q2);
+                const float2_ ds = __builtin_elementwise_fma(ee, hh, gg);
+                const float2_ cc = (ds * ds) * ds;
+                const float2_ r0 = (yy * yy) * yy;
+                const float2_ one = {1.0f, 1.0f};
+                const float2_ e0 = __builtin_elementwise_fma(-cc, r0, one);
+                const float2_ r1 = __builtin_elementwise_fma(e0, r0, r0);
+                const float2_ e1 = __builtin_elementwise_fma(-cc, r1, one);
+                const float2_ inv = __builtin_elementwise_fma(e1, r1, r1);
+                F = F + (da * m) * inv.x;
+                F = F + (db * m) * inv.y;
+                (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
             } else {           // same work with scalar (non-packed) ops only: 22 VALU
                 float dx, dy, a2, b2, mx, my, tx, ty;
                 asm volatile(
@@ -100,7 +124,7 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out
                     : "vcc", "s10", "s11");
             }
             rec.x += 1e-3f;
-            if (MODE == 2) recb.x += 1e-3f;
+            if (MODE == 2 || MODE == 3) recb.x += 1e-3f;
         }
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -135,5 +159,6 @@ int main() {
     run<0>("packed, serial chain", d_cyc, d_out);
     run<1>("scalar ops only", d_cyc, d_out);
     run<2>("chain packed across 2", d_cyc, d_out);
+    run<3>("... and no v_rcp", d_cyc, d_out);
     return 0;
 }
