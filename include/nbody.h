@@ -152,7 +152,7 @@ typedef struct nbody_ctx_desc {
     const void* comm_id;    /* world>1 with RCCL: 128-byte id from nbody_comm_unique_id on rank 0       */
     int kernel_variant;     /* 0 = automatic (by own-range size); tuning / A-B testing only: 1 general kernel, */
                             /* 11/12/14/18 one-lane..eight-lanes-per-body kernel, 31/32 its 256-thread form,   */
-                            /* 40 producer/consumer kernel, 50 ring-of-waves kernel.  fp64: 1 selects the       */
+                            /* 40 producer/consumer kernel, 50 ring-of-waves kernel (51-59: its tuning forms). fp64: 1 selects the */
                             /* general kernel, anything else the fp64 production kernel                         */
 } nbody_ctx_desc;
 
@@ -259,6 +259,17 @@ int nbody_selftest_ieee_f32(int device, uint64_t mismatches[3]);
  * sqrt and 1/x on inputs_per_mode inputs of each of three families of its guarded domain [2^-500, 2^500] (random;
  * mantissas next to powers of two; perfect squares +- 4 ulps).  mismatches = {sqrt, 1/d^3}; both must be 0. */
 int nbody_selftest_chain_f64(int device, uint64_t inputs_per_mode, uint64_t mismatches[2]);
+
+/* The ring kernel's hand-off relies on a lane's 16-byte LDS record being written (ds_write_b128) and read
+ * (ds_read_b128) in one LDS-array cycle, i.e. never seen half old, half new.  512 workgroups: one wave rewrites its 64
+ * records `iters` times while seven waves poll them.  result = {torn records seen, sequence numbers going
+ * backwards, records read}; the first two must be 0. */
+int nbody_selftest_lds_record(int device, int iters, uint64_t result[3]);
+
+/* Tuning aid (kernel_variant 58 only): cycle totals of the ring kernel's phases since upload, summed over waves:
+ * {evaluate, wait, chain+publish, window check, polls, turns, shader clocks of one wave's life, the same in 100 MHz
+ * ticks}. */
+int nbody_debug_ring_probe(nbody_ctx* ctx, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

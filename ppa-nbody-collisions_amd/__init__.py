@@ -124,6 +124,8 @@ SYMBOLS = {
     "nbody_launch_move_bodies_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp]),
     "nbody_selftest_ieee_f32": (_i, [_i, ctypes.POINTER(ctypes.c_uint64 * 3)]),
     "nbody_selftest_chain_f64": (_i, [_i, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64 * 2)]),
+    "nbody_selftest_lds_record": (_i, [_i, _i, ctypes.POINTER(ctypes.c_uint64 * 3)]),
+    "nbody_debug_ring_probe": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64 * 8)]),
 }
 
 
@@ -368,6 +370,11 @@ class Stepper:
 
     def set_kernel_timing(self, enable=True):
         _check(lib.nbody_set_kernel_timing(self._ctx, int(enable)))
+
+    def ring_probe(self):
+        out = (ctypes.c_uint64 * 8)()
+        _check(lib.nbody_debug_ring_probe(self._ctx, ctypes.byref(out)))
+        return list(out)
 
     def stats(self):
         s = Stats()

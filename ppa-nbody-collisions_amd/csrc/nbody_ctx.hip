@@ -105,6 +105,7 @@ struct nbody_ctx {
     size_t slot_bytes = 0;
     int* blk_counts = nullptr;
     Meta* meta = nullptr;
+    Meta* meta_all = nullptr;       // RCCL contexts: every rank's Meta, all-gathered by nbody_download
     Counters* counters = nullptr;
     Event* events = nullptr;
     int ev_cap = 0;
@@ -116,6 +117,9 @@ struct nbody_ctx {
     Meta* h_meta = nullptr;     // pinned
     Meta* h_meta_async = nullptr;   // pinned; refreshed by an un-waited D2H copy after every step
     Counters* h_counters = nullptr;
+    Counters* h_counters_async = nullptr;   // pinned; refreshed like h_meta_async (nbody_step looks at .errors)
+    int spin_limit = 1 << 24;       // ring kernel: polls before a hand-off wait is declared failed
+    bool device_failed = false;     // sticky until the next nbody_upload: a kernel reported a failed hand-off wait
     int n_upper = 0;            // host-side upper bound of the global count (exact after a sync)
     int own_upper = 0;          // upper bound of the own count
     bool uploaded = false;
@@ -131,8 +135,16 @@ struct nbody_ctx {
 
 namespace {
 
+// Polls of a hand-off record before the ring kernel declares the wait failed (a poll is ~100 cycles: the default is
+// about a second).  NBODY_RING_SPIN_LIMIT shrinks it so that the failure path can be exercised (tests).
+int ring_spin_limit() {                                    // read when a context is created
+    const char* e = getenv("NBODY_RING_SPIN_LIMIT");
+    const long v = e ? strtol(e, nullptr, 10) : 0;
+    return v > 0 && v < (1l << 30) ? (int)v : (1 << 24);
+}
+
 template <typename T>
-StepParams<T> make_params(const nbody_ctx_desc& d) {
+StepParams<T> make_params(const nbody_ctx_desc& d, int spin_limit = 1 << 24) {
     StepParams<T> p;
     p.dt = (T)d.timestep;            // cfg values are floats; double holds them exactly
     p.growth = (T)d.growthRate;
@@ -142,6 +154,7 @@ StepParams<T> make_params(const nbody_ctx_desc& d) {
     p.wall_hi_y = (T)d.fieldHeight;
     p.wall_lo_y = (T)(-d.fieldHeight);
     p.literal = d.semantics == NBODY_LITERAL;
+    p.spin_limit = spin_limit;
     return p;
 }
 
@@ -159,12 +172,24 @@ int resolve_timing(nbody_ctx* c) {
     return NBODY_OK;
 }
 
+// The convention of CUDA_SYNC_CHECK (src/nbody.cu:20-33): a failure on the device surfaces at the next point where
+// the host looks.  The only in-kernel failure is a ring hand-off wait that gave up (the kernel then poisons its
+// output with NaNs); once seen it is sticky until the next nbody_upload.
+int device_failure(nbody_ctx* c, unsigned long long errors) {
+    if (errors != 0) c->device_failed = true;
+    if (!c->device_failed) return NBODY_OK;
+    return nbody_fail(NBODY_ERR_HIP, "device reported %llu in-kernel hand-off time-out(s): the state is poisoned (NaN), "
+                                     "upload again", errors);
+}
+
+// Synchronises the stream and refreshes the host copies of Meta and Counters; fails if the device reported a failure.
 int read_meta(nbody_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->h_meta, c->meta, sizeof(Meta), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_upper = c->h_meta->n;
     c->own_upper = c->h_meta->cnt;
-    return NBODY_OK;
+    return device_failure(c, c->h_counters->errors);
 }
 
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
@@ -210,10 +235,16 @@ inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bo
     else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-inline void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+template <int kW, int kT, int kSleep, bool kProbe>
+void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe>), dim3(grid), dim3(kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe>), dim3(grid), dim3(kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+}
+inline void launch_ring_r1(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+    const int grid = nblocks * 2;
+    if (log) hipLaunchKernelGGL((forces_ring_r1_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_r1_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
 template <>
@@ -230,7 +261,12 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
         case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
         case 40: launch_pc8(c, p, nblocks, log); return;
-        case 50: launch_ring(c, p, nblocks, log); return;
+        case 50: launch_ring<8, 32, 0, false>(c, p, nblocks, log); return;
+        case 51: launch_ring<8, 32, 1, false>(c, p, nblocks, log); return;      // tuning: s_sleep in the poll
+        case 52: launch_ring<4, 32, 0, false>(c, p, nblocks, log); return;      // tuning: 4 waves per ring
+        case 53: launch_ring<8, 16, 0, false>(c, p, nblocks, log); return;      // tuning: turns of 16 positions
+        case 58: launch_ring<8, 32, 0, true>(c, p, nblocks, log); return;       // tuning: in-kernel phase stamps
+        case 59: launch_ring_r1(c, p, nblocks, log); return;                    // round-1 form, A/B only
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
@@ -239,13 +275,13 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //   >= 8k bodies   : ring of 8 waves per 64 bodies (11.6 vs 12.5 ms at 64k own bodies, 6.4 vs 7.1 ms at 32k)
     //   below          : 8-wave producer/consumer workgroups per 64 bodies
     if (c->own_upper >= 100000) launch_v3w<1, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 8192) launch_ring(c, p, nblocks, log);
+    else if (c->own_upper >= 8192) launch_ring<8, 32, 0, false>(c, p, nblocks, log);
     else launch_pc8(c, p, nblocks, log);
 }
 
 template <typename T>
 int launch_compute(nbody_ctx* c) {
-    const StepParams<T> p = make_params<T>(c->desc);
+    const StepParams<T> p = make_params<T>(c->desc, c->spin_limit);
     {
         const int cnt_seen = *(volatile int*)&c->h_meta_async->cnt, n_seen = *(volatile int*)&c->h_meta_async->n;
         if (cnt_seen > 0 && cnt_seen < c->own_upper) c->own_upper = cnt_seen;
@@ -312,6 +348,7 @@ int commit_phase(nbody_ctx* c) {
     // Counts only shrink, so a count read back late is still an upper bound: copy Meta to pinned memory
     // without waiting and let later launches size their grids / pick their kernel from whatever has landed.
     HIP_TRY(hipMemcpyAsync(c->h_meta_async, c->meta, sizeof(Meta), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_counters_async, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     return NBODY_OK;
 }
 
@@ -324,11 +361,12 @@ void free_all(nbody_ctx* c) {
     hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
     if (c->gather && c->gather != c->slot) hipFree(c->gather);
     hipFree(c->slot);
-    hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
+    hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_meta) hipHostFree(c->h_meta);
     if (c->h_meta_async) hipHostFree(c->h_meta_async);
     if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->h_counters_async) hipHostFree(c->h_counters_async);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -376,6 +414,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     if (!c) return nbody_fail(NBODY_ERR_NOMEM, "nbody_ctx_create: out of host memory");
     c->desc = *d;
     c->desc.comm_id = nullptr;
+    c->spin_limit = ring_spin_limit();
     c->real_bytes = d->precision == NBODY_F64 ? 8 : 4;
     c->rec_bytes = 4 * c->real_bytes;
     c->cap = d->capacity;
@@ -406,6 +445,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     else c->gather = c->slot;
     CTX_TRY(hipMalloc((void**)&c->blk_counts, sizeof(int) * (size_t)(c->cap_own / kCompactBlock + 2)));
     CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
+    if (use_comm) CTX_TRY(hipMalloc((void**)&c->meta_all, sizeof(Meta) * (size_t)d->world));
     CTX_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
     CTX_TRY(hipMalloc((void**)&c->events, sizeof(Event) * (size_t)c->ev_cap));
     // on the context's own stream and waited for: hipMemset() on device memory runs on the NULL stream and may
@@ -419,6 +459,9 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     CTX_TRY(hipHostMalloc((void**)&c->h_meta, sizeof(Meta), hipHostMallocDefault));
     CTX_TRY(hipHostMalloc((void**)&c->h_meta_async, sizeof(Meta), hipHostMallocDefault));
     CTX_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc((void**)&c->h_counters_async, sizeof(Counters), hipHostMallocDefault));
+    memset(c->h_counters, 0, sizeof(Counters));
+    memset(c->h_counters_async, 0, sizeof(Counters));
 #undef CTX_TRY
 
     if (use_comm) {
@@ -479,6 +522,9 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_upper = n; c->own_upper = cnt;
+    memset(c->h_counters, 0, sizeof(Counters));
+    memset(c->h_counters_async, 0, sizeof(Counters));
+    c->device_failed = false;
     c->uploaded = true;
     c->steps = 0;
     c->force_ms = 0; c->force_launches = 0;
@@ -510,6 +556,10 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
                     (void)hipGetLastError();
                 }
             }
+    for (int g = 0; g < world; ++g) {
+        int failed = device_failure(ctxs[g], *(volatile unsigned long long*)&ctxs[g]->h_counters_async->errors);
+        if (failed != NBODY_OK) return failed;
+    }
     std::vector<hipEvent_t> ready(world), done(world);
     for (int g = 0; g < world; ++g) {
         HIP_TRY(hipSetDevice(ctxs[g]->desc.device));
@@ -581,6 +631,9 @@ int nbody_step(nbody_ctx* c, int nsteps) {
     if (c->desc.world > 1 && (c->desc.flags & NBODY_FLAG_GROUP_EXCHANGE))
         return nbody_fail(NBODY_ERR_STATE, "group context: step it with nbody_group_step");
     HIP_TRY(hipSetDevice(c->desc.device));
+    // asynchronous: a device failure of an earlier step is reported as soon as its counters have landed
+    int failed = device_failure(c, *(volatile unsigned long long*)&c->h_counters_async->errors);
+    if (failed != NBODY_OK) return failed;
     for (int s = 0; s < nsteps; ++s) {
         int rc = compute_phase(c);
         if (rc != NBODY_OK) return rc;
@@ -595,9 +648,9 @@ int nbody_step(nbody_ctx* c, int nsteps) {
 int nbody_sync(nbody_ctx* c) {
     if (!c) return nbody_fail(NBODY_ERR_INVALID, "NULL context");
     HIP_TRY(hipSetDevice(c->desc.device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipGetLastError());
-    return NBODY_OK;
+    return c->uploaded ? read_meta(c) : (hipStreamSynchronize(c->stream) == hipSuccess ? NBODY_OK
+                                          : nbody_fail(NBODY_ERR_HIP, "hipStreamSynchronize failed"));
 }
 
 int nbody_ctx_info(nbody_ctx* c, nbody_ctx_desc* desc_out, int64_t* steps) {
@@ -670,13 +723,10 @@ int nbody_download(nbody_ctx* c, void* block, int* n_out) {
                                   c->stream));
         // every rank's {lo, cnt}: a second, tiny all-gather of the device-resident Meta (the slot headers hold
         // counts only after a step has run)
-        Meta* d_all = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_all, sizeof(Meta) * c->desc.world));
-        RCCL_TRY(g_rccl.AllGather(c->meta, d_all, sizeof(Meta), kNcclInt8, c->comm, c->stream));
+        RCCL_TRY(g_rccl.AllGather(c->meta, c->meta_all, sizeof(Meta), kNcclInt8, c->comm, c->stream));
         std::vector<Meta> h_all(c->desc.world);
-        HIP_TRY(hipMemcpyAsync(h_all.data(), d_all, sizeof(Meta) * c->desc.world, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_all.data(), c->meta_all, sizeof(Meta) * c->desc.world, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-        hipFree(d_all);
         for (int g = 0; g < c->desc.world; ++g) {
             HIP_TRY(hipMemcpy(V + 2 * rb * (size_t)h_all[g].lo,
                               c->gather + (size_t)g * c->cap_own * 2 * rb, (size_t)h_all[g].cnt * 2 * rb,
@@ -697,6 +747,8 @@ int nbody_render_image(nbody_ctx* c, unsigned char* img, int width, int height) 
     if (!c || !img || width <= 0 || height <= 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_render_image: bad argument");
     if (!c->uploaded) return nbody_fail(NBODY_ERR_STATE, "nbody_render_image before nbody_upload");
     HIP_TRY(hipSetDevice(c->desc.device));
+    int rc0 = read_meta(c);
+    if (rc0 != NBODY_OK) return rc0;
     const size_t bytes = (size_t)width * height;
     if (bytes > c->d_img_bytes) {
         hipFree(c->d_img);
@@ -752,13 +804,8 @@ int nbody_get_stats(nbody_ctx* c, nbody_stats* out) {
     HIP_TRY(hipSetDevice(c->desc.device));
     int rc = read_meta(c);
     if (rc != NBODY_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     rc = resolve_timing(c);
     if (rc != NBODY_OK) return rc;
-    if (c->h_counters->errors != 0)
-        return nbody_fail(NBODY_ERR_HIP, "device reported %llu in-kernel hand-off time-outs: results are invalid",
-                          (unsigned long long)c->h_counters->errors);
     out->steps = c->steps;
     out->pairs = (int64_t)c->h_counters->pairs;
     out->force_kernel_ms = c->force_ms;
@@ -803,6 +850,33 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const fl
     hipLaunchKernelGGL(ref_layout_move_f32, dim3(numBlocks), dim3(kTile), 0, (hipStream_t)stream, d_bodyData,
                        d_updM, d_updR, numBodies, timestep);
     HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_debug_ring_probe(nbody_ctx* c, uint64_t out[8]) {
+    if (!c || !out) return nbody_fail(NBODY_ERR_INVALID, "nbody_debug_ring_probe: NULL");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    int rc = read_meta(c);
+    if (rc != NBODY_OK) return rc;
+    for (int k = 0; k < 8; ++k) out[k] = c->h_counters->probe[k];
+    return NBODY_OK;
+}
+
+int nbody_selftest_lds_record(int device, int iters, uint64_t result[3]) {
+    if (!result || iters <= 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_selftest_lds_record: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return nbody_fail(NBODY_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 3 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(selftest_lds_record, dim3(512), dim3(8 * kWave), 0, 0, d, iters);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[3];
+    HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(d);
+    for (int k = 0; k < 3; ++k) result[k] = h[k];
     return NBODY_OK;
 }
 

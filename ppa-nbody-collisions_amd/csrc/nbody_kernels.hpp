@@ -48,6 +48,7 @@ struct Counters {
     unsigned long long pairs;     // ordered pairs evaluated (this rank)
     unsigned long long events;    // events logged (may exceed capacity: overflow is counted, not stored)
     unsigned long long errors;    // device-side failures (an in-kernel hand-off wait timed out)
+    unsigned long long probe[8];  // tuning builds of the ring kernel: cycle totals per phase (kProbe)
 };
 
 // Send slot of one rank for the per-step exchange: header + compacted survivors of the own range.
@@ -65,6 +66,7 @@ struct StepParams {
     T wall_hi_x, wall_lo_x;   // (T)fieldWidth, (T)(-fieldWidth): the int->real conversions of :256-257
     T wall_hi_y, wall_lo_y;
     int literal;              // 1: reference index semantics, 0: clean all-pairs
+    int spin_limit;           // ring kernel: polls of a hand-off record before the wait is declared failed
 };
 
 template <typename T> __device__ __forceinline__ T ieee_sqrt(T x);
@@ -887,6 +889,393 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
 // ---------------------------------------------------------------------------------------------------------
 // Force + collision + drift kernel, variant "ring" (fp32): for own ranges with fewer chains than the chip has lanes.
 //
+// A workgroup of kW waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
+// turns of kT positions and the turns go round the waves: wave w takes turns w, w + kW, w + 2 kW, ...  For its turn a
+// wave (1) has the tile entries its lanes need loaded straight from the replica into a private LDS window (direct-to-LDS
+// loads issued one own turn ahead), (2) evaluates the kT terms of every lane into registers - 12 of the 13 instructions
+// per pair, dependent on nothing -, (3) waits until the wave before it has published the running state of the chain
+// {fx, fy, deleted, mass/radius version} in LDS, (4) adds its kT terms to it in walk order (or, for a flagged lane / a
+// special tile, runs the general code on the kT positions), and (5) publishes the state for the next wave.  So the
+// ordered chain of every body passes through all waves in turn, each holding it only for kT adds, while the others
+// evaluate terms: no wave is a dedicated (half idle) chain wave, no term goes through LDS, there is no workgroup
+// barrier in the loop, and the instruction count per pair is that of the one-lane kernel plus the hand-off.
+//
+// Hand-off = ONE 16-byte LDS record per lane {fx, fy, seq, flags}: written with one ds_write_b128, polled with one
+// ds_read_b128.  The LDS services a lane's whole 16 bytes in one array cycle for both instructions (MI355X_MICROARCH.md,
+// LDS table: lane groups), so a reader sees a record entirely old or entirely new (nbody_selftest_lds_record checks
+// exactly this); seq == tau means "the state after turn tau - 1".  Absorbed mass / radius change rarely: they travel
+// in a second record that is rewritten only when they change, with a per-lane version number in `flags`.
+// Round 1 lessons built in (profiles/r02_ring_*): the sequence number used to be accessed through a generic pointer
+// (flat_load / flat_store + s_waitcnt vmcnt(0): every poll waited for the window prefetch), and the direct-to-LDS loads
+// were compiler builtins, which make hipcc wait for them (vmcnt(0)) before ANY later LDS read: the prefetch was never in
+// flight during a turn.  Both are typed LDS accesses / inline assembly now and the only vmcnt wait is the one below.
+// A wait that exceeds p.spin_limit polls is reported (Counters::errors, sticky on the host) and POISONS the chain:
+// the state becomes NaN and a dead mark travels with the sequence number, so every later turn passes at once and
+// the step's output cannot be mistaken for a result.
+// First / last tile of a walk (self skip, truncation), the clean semantics' own tile and windows with unbounded
+// coordinates are done by the general code with records fetched from the replica.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* LdsPtr;
+typedef int Int4 __attribute__((ext_vector_type(4)));
+typedef float Float2 __attribute__((ext_vector_type(2)));
+typedef volatile __attribute__((address_space(3))) Int4* LdsInt4Ptr;
+typedef volatile __attribute__((address_space(3))) Float2* LdsFloat2Ptr;
+
+constexpr int kRingDeadSeq = 0x40000000;                   // sequence number of a poisoned chain
+
+// 16 bytes per active lane from global memory straight into LDS at lds_base + 16 * lane (gfx950 LDS-DMA).  Inline
+// assembly on purpose: hipcc tracks the builtin form as a writer of all LDS and waits vmcnt(0) before the next LDS read.
+// M0 is written by nothing else in these kernels (gfx9 DS instructions do not use it).
+__device__ __forceinline__ void load_to_lds_b128(const void* base, unsigned byte_offset, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                 ::"s"(lds_base), "v"(byte_offset), "s"(base) : "memory");
+}
+// One record from the replica WITHOUT the compiler knowing that a vector-memory operation happened: a tracked load
+// inside the turn loop makes hipcc guard later register writes and LDS reads with s_waitcnt vmcnt(0), which also
+// waits for the window prefetch.  Rare path (special tiles) only.
+__device__ __forceinline__ Rec<float> load_rec_untracked(const Rec<float>* src) {
+    typedef float Float4 __attribute__((ext_vector_type(4)));
+    Float4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
+    return Rec<float>{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
+
+template <bool kLog, int kW, int kT, int kSleep, bool kProbe>
+__global__ __launch_bounds__(kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
+                     Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
+                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
+    typedef float T;
+    typedef Pair<float>::type V2;
+    static_assert(kTile % kT == 0 && kT % 8 == 0 && kT <= kWave, "turn length");
+    constexpr int kTurnsPerTile = kTile / kT;
+    static_assert(kW % kTurnsPerTile == 0, "a wave's successive turns are whole tiles apart");
+    constexpr int kTilesPerRound = kW / kTurnsPerTile;
+    constexpr int kWin = kWave + kT;                       // window entries a turn can touch (kWin - 1 used)
+    __shared__ Rec<T> win[kW][2][kWin];                    // per wave, double buffered
+    __shared__ Int4 hand[kWave];                           // {fx, fy, seq, flags = version << 1 | deleted} per lane
+    __shared__ Float2 hand_m[kWave];                       // {mnew, rnew}, rewritten only when they change
+    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int l = tid % kWave;
+    const int wg = blockIdx.x;
+    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
+    const int t0 = (wg % 2) * kWave;
+    const int t = t0 + l;                                  // threadIdx.x of this lane's body in the reference
+    const long long blk0 = (long long)b * kTile;
+    if (blk0 + t0 >= (long long)lo + cnt) return;
+    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
+    const bool lit = p.literal != 0;
+    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
+    const int nturns = ntiles * kTurnsPerTile;
+
+    const long long i64 = blk0 + t;
+    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
+    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
+    BodyAcc<T> a;
+    if (mine) {
+        const Rec<T> me = J[i];
+        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
+    } else {
+        a.xi = a.yi = a.mi = a.ri = 0;
+    }
+    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
+    int mver = 0;                                          // version of {mnew, rnew} this wave holds
+    const int spin_limit = __builtin_amdgcn_readfirstlane(p.spin_limit);   // (kept out of the poll loop's reach)
+    bool dead = false;
+    int timeouts = 0;
+    const bool lane_ok = !active || ((abs_(a.xi) < kCoordBound) && (abs_(a.yi) < kCoordBound));
+    const bool wave_ok = __ballot(!lane_ok) == 0ull;
+    const bool wave_r0 = __ballot(active && not_plus_zero(a.ri)) == 0ull;
+    unsigned long long pairs = 0;
+    const LdsInt4Ptr hand_l = (LdsInt4Ptr)&hand[l];
+    const LdsFloat2Ptr hand_m_l = (LdsFloat2Ptr)&hand_m[l];
+    if (tid < kWave) *hand_l = Int4{0, 0, 0, 0};
+    __syncthreads();                                       // the only workgroup barrier: seq = 0 everywhere
+    unsigned long long pr_eval = 0, pr_wait = 0, pr_chain = 0, pr_check = 0, pr_polls = 0, pr_t0 = 0, pr_r0 = 0;
+    if (kProbe) { pr_t0 = __builtin_readcyclecounter(); pr_r0 = wall_clock64(); }
+
+    // First body of the tile of this wave's current turn (literal: cyclic tile b + kk), kept incrementally: a wave
+    // moves on by kW turns = kTilesPerRound tiles at a time, and a division here would cost as much as the turn's
+    // arithmetic.
+    auto tile_start_slow = [&](int kk) -> long long {
+        if (!lit) return (long long)kk * kTile;
+        return (blk0 % N + (long long)kk * kTile) % N;
+    };
+    auto round_on = [&](long long st) -> long long {
+        st += kTilesPerRound * kTile;
+        if (lit) while (st >= N) st -= N;                  // a next turn exists only when N > kTilesPerRound tiles: once
+        return st;
+    };
+    auto tile_len = [&](int kk, long long st) -> int {
+        if (lit) return (kk == nb - 1) ? N % (kTile + 1) : kTile;             // :194 (quirk Q1)
+        return (N - st) < kTile ? (int)(N - st) : kTile;
+    };
+    // is every position of tile kk an ordinary pair for every lane of the workgroup?
+    auto interior = [&](int kk, long long st) -> bool {
+        return lit ? (kk >= 1 && kk <= nb - 2) : (tile_len(kk, st) == kTile && kk != b);
+    };
+    // The window of a fast turn: entry j of the window is tile entry (wbase0 + off0 + j) mod 128, and off0 is the same
+    // for every turn of a wave (kW is a multiple of the turns per tile): the tile entries this lane fetches are two
+    // per-lane constants, the body index is that plus the tile's first body, wrapped once (interior tiles: N >= 384).
+    const int wbase0 = lit ? t0 : 0;                       // literal: lane l reads window[l + r]; clean: window[r]
+    const int nwin = lit ? (kWave + kT - 1) : kT;          // entries of the window that are used
+    const unsigned e0 = (unsigned)(wbase0 + (w % kTurnsPerTile) * kT + l) & (kTile - 1);
+    const unsigned e1 = e0 ^ kWave;                        // the entry 64 further on
+    auto window_offset = [&](long long st, unsigned e) -> unsigned {   // byte offset of the body's record in J
+        const unsigned src = (unsigned)st + e;
+        const unsigned wrapped = src - (unsigned)N;        // huge when src < N
+        return (src < wrapped ? src : wrapped) * (unsigned)sizeof(Rec<T>);
+    };
+    // The window of turn tau, loaded from the replica STRAIGHT INTO LDS (lane l's 16 bytes land at base + 16 l), so
+    // the prefetch holds no registers and stays in flight for a whole turn.  Returns whether the turn can take
+    // the fast path as far as is known before the data has arrived.
+    auto issue_window = [&](int tau, long long st, int buf) -> bool {
+        if (tau >= nturns) return false;
+        const int kk = tau / kTurnsPerTile;
+        if (!(interior(kk, st) && wave_ok)) return false;
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0]));
+        if (l < nwin) load_to_lds_b128(J, window_offset(st, e0), base);
+        if (l + kWave < nwin) load_to_lds_b128(J, window_offset(st, e1), base + kWave * (unsigned)sizeof(Rec<T>));
+        return true;
+    };
+    // after the loads have landed: are all coordinates of the window bounded, is some radius not +0.0f
+    struct WindowState { bool fast, rnz; };
+    auto check_window = [&](bool issued, int buf) -> WindowState {
+        if (!issued) return WindowState{false, true};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // issued a whole turn ago
+        __builtin_amdgcn_wave_barrier();
+        Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
+        if (l < nwin) r0 = win[w][buf][l];
+        if (l + kWave < nwin) r1 = win[w][buf][l + kWave];
+        const bool bad0 = !((abs_(r0.x) < kCoordBound) && (abs_(r0.y) < kCoordBound));
+        const bool bad1 = !((abs_(r1.x) < kCoordBound) && (abs_(r1.y) < kCoordBound));
+        WindowState ws;
+        ws.fast = __ballot(bad0 || bad1) == 0ull;
+        // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
+        ws.rnz = __ballot(not_plus_zero(r0.r) || not_plus_zero(r1.r)) != 0ull;
+        return ws;
+    };
+    // one walk position by the general code, record fetched from the replica
+    auto general_at = [&](int kk, long long st, int L, int off) {
+        int sidx;
+        long long j;
+        if (lit) {
+            if (kk == 0 && off == 0) return;                                   // :200-204
+            sidx = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L); // :207
+            j = st + sidx;
+            if (j >= N) j %= N;
+        } else {
+            j = st + off;
+            if (j == i64) return;
+        }
+        interact<T, kLog>(a, load_rec_untracked(J + j), p.growth, i, (int)j, ev, ev_cap, ctr, step);
+    };
+
+    long long st = tile_start_slow(w / kTurnsPerTile);
+    int buf = 0;
+    int flags_in = 0;                                      // `flags` of the last record this wave received
+    // {mnew, rnew, deleted} are only needed by the general code and the epilogue: brought up to date from the last
+    // received flags (and the rare record) right before those, never on the fast path
+    auto sync_rare = [&]() {
+        a.deleted = flags_in & 1;
+        if ((flags_in >> 1) != mver) {                     // this lane's mass / radius changed in an earlier turn
+            const Float2 hm = *hand_m_l;
+            a.mnew = hm.x; a.rnew = hm.y;
+            mver = flags_in >> 1;
+        }
+    };
+    WindowState cur = check_window(issue_window(w, st, buf), buf);
+    for (int tau = w; tau < nturns; tau += kW) {
+        unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
+        if (kProbe) pt0 = __builtin_readcyclecounter();
+        const int kk = tau / kTurnsPerTile;
+        const int off0 = (tau % kTurnsPerTile) * kT;
+        const int L = tile_len(kk, st);
+        const bool fast = cur.fast;
+        const long long st_next = round_on(st);
+        const bool issued_next = issue_window(tau + kW, st_next, buf ^ 1);   // in flight for the whole turn
+        // (2) the kT terms of this turn
+        V2 term[kT];
+        unsigned long long flag = 0;
+        if (fast) {
+            const Rec<T>* walk = &win[w][buf][lit ? l : 0];
+            V2 own;
+            own.x = a.xi; own.y = a.yi;
+            auto evaluate = [&](auto r0_tag) {
+                constexpr bool kR0 = decltype(r0_tag)::value;
+                constexpr int kG = (kR0 && kT <= 16) ? 8 : 4;   // reads per batch: the terms already take 2 kT VGPRs
+#pragma unroll
+                for (int r0 = 0; r0 < kT; r0 += kG) {
+                    Rec<T> rec[kG];
+#pragma unroll
+                    for (int u = 0; u < kG; ++u) rec[u] = walk[r0 + u];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < kG; u += 2) {
+                        const Rec<T> ba = rec[u], bb = rec[u + 1];
+                        V2 pa, pb;
+                        pa.x = ba.x; pa.y = ba.y;
+                        pb.x = bb.x; pb.y = bb.y;
+                        const V2 da = pa - own, db = pb - own;
+                        const V2 sa = da * da, sb = db * db;
+                        V2 d2, q;
+                        d2.x = add_unmerged(sa.x, sa.y);
+                        d2.y = add_unmerged(sb.x, sb.y);
+                        q.x = kFastLo; q.y = kFastLo;
+                        if (!kR0) {
+                            V2 rs;
+                            rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
+                            q = __builtin_elementwise_fma(rs, rs, q);          // flag only
+                        }
+                        flag |= le_mask(d2.x, q.x);
+                        flag |= le_mask(d2.y, q.y);
+                        const V2 inv = fast_inv_cube2(d2);
+                        term[r0 + u] = (da * ba.m) * inv.x;
+                        term[r0 + u + 1] = (db * bb.m) * inv.y;
+                    }
+                }
+            };
+            if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
+            else evaluate(std::false_type{});
+        }
+        if (kProbe) pt1 = __builtin_readcyclecounter();
+        // (3) the state after turn tau - 1.  Polled at raised priority: a poll is one LDS read plus scalar work, it
+        // takes next to nothing from the vector pipelines of the waves that are evaluating, and the chain moves on
+        // within one LDS round trip of the record being written.
+        Int4 h = Int4{0, 0, 0, 0};
+        bool timed_out = false;
+        __builtin_amdgcn_s_setprio(3);
+        if (tau > 0) {
+            int spins = 0;
+            for (;;) {
+                h = *hand_l;                               // one ds_read_b128
+                if (__ballot(h.z < tau) == 0ull) break;
+                if (++spins > spin_limit) { timed_out = true; break; }
+                if (kSleep > 0) __builtin_amdgcn_s_sleep(kSleep);
+            }
+            if (kProbe) pr_polls += spins + 1;
+            flags_in = h.w;
+        }
+        if (kProbe) pt2 = __builtin_readcyclecounter();
+        // (4) + (5).  The common case - a fast turn, no flagged lane, the sequence number the expected one - is kept as
+        // short as the arithmetic allows, because it is the serial part of the whole workgroup: 2 kT dependent adds
+        // (x and y chains interleaved: scalar adds need no wait states between dependent instructions, packed ones
+        // do), then one LDS write; `flags` passes through untouched.
+        const bool plain = fast && flag == 0ull && !dead && !timed_out && __ballot(h.z != tau) == 0ull;
+        if (plain) {
+            float fx = __int_as_float(h.x), fy = __int_as_float(h.y);
+#pragma unroll
+            for (int r = 0; r < kT; ++r) {
+                fx = fx + term[r].x;
+                asm("" : "+v"(fx));                        // keeps hipcc from pairing the two adds into one v_pk_add_f32
+                fy = fy + term[r].y;
+            }
+            if (tau + 1 < nturns)
+                *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, flags_in};
+            __builtin_amdgcn_s_setprio(0);
+            a.fx = fx; a.fy = fy;
+            if (active) pairs += kT;
+        } else {
+            a.fx = __int_as_float(h.x); a.fy = __int_as_float(h.y);
+            sync_rare();
+            timeouts += timed_out ? 1 : 0;
+            dead = dead || timed_out || __ballot(h.z >= kRingDeadSeq) != 0ull;
+            const unsigned m_before = __float_as_uint(a.mnew), r_before = __float_as_uint(a.rnew);
+            if (fast) {
+                if (active) {
+                    if ((flag >> l) & 1ull) {
+#pragma unroll 1
+                        for (int r = 0; r < kT; ++r) {
+                            const int off = off0 + r;
+                            const int sidx = lit ? ((t + off) & (kTile - 1)) : off;
+                            long long j = st + sidx;
+                            if (j >= N) j -= N;
+                            interact<T, kLog>(a, win[w][buf][(lit ? l : 0) + r], p.growth, i, (int)j, ev, ev_cap, ctr, step);
+                        }
+                    } else {
+                        float fx = a.fx, fy = a.fy;
+#pragma unroll
+                        for (int r = 0; r < kT; ++r) {
+                            fx = add_unmerged(fx, term[r].x);
+                            fy = add_unmerged(fy, term[r].y);
+                        }
+                        a.fx = fx; a.fy = fy;
+                    }
+                    pairs += kT;
+                }
+            } else if (active) {
+                const int hi = off0 + kT < L ? off0 + kT : L;
+                for (int off = off0; off < hi; ++off) general_at(kk, st, L, off);
+                if (lit) {
+                    if (hi > off0) pairs += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
+                } else {
+                    for (int off = off0; off < hi; ++off) pairs += (st + off != i64) ? 1 : 0;
+                }
+            }
+            if (dead) {                                    // a hand-off wait gave up somewhere before: poison, never a result
+                a.fx = a.fy = a.mnew = a.rnew = __builtin_nanf("");
+                a.deleted = 0;
+            }
+            // publish: the rare record first, then the one the next wave polls (a wave's LDS operations execute in order)
+            if (__float_as_uint(a.mnew) != m_before || __float_as_uint(a.rnew) != r_before) {
+                *hand_m_l = Float2{a.mnew, a.rnew};
+                mver += 1;
+            }
+            flags_in = (mver << 1) | (a.deleted & 1);      // what this wave now knows to be current
+            if (tau + 1 < nturns)
+                *hand_l = Int4{(int)__float_as_uint(a.fx), (int)__float_as_uint(a.fy), dead ? kRingDeadSeq : tau + 1,
+                               flags_in};
+            __builtin_amdgcn_s_setprio(0);
+        }
+        if (kProbe) pt3 = __builtin_readcyclecounter();
+        // the prefetched window of this wave's next turn
+        buf ^= 1;
+        st = st_next;
+        cur = check_window(issued_next, buf);
+        if (kProbe) {
+            pr_eval += pt1 - pt0; pr_wait += pt2 - pt1; pr_chain += pt3 - pt2;
+            pr_check += __builtin_readcyclecounter() - pt3;
+        }
+    }
+    if ((nturns - 1) % kW == w) sync_rare();               // the wave of the last turn holds the final state
+    // Nothing above this line in the loop is a memory access the compiler tracks in vmcnt (the window loads and the
+    // general code's record loads are inline assembly with their own waits): hipcc therefore places no vmcnt wait in
+    // the loop, and the only one there is check_window's, for a prefetch issued a whole turn earlier.
+    if (mine && (nturns - 1) % kW == w) {                  // the wave that took the last turn: epilogue
+        const int q = i - lo;
+        const Vec2<T> v = Vown[q];
+        if (active) {
+            Rec<T> out; Vec2<T> vout;
+            finish_body<T>(a, v, p, out, vout);
+            S_J[q] = out;
+            S_V[q] = vout;
+        } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
+            S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
+            S_V[q] = v;
+        }
+    }
+    if (timeouts != 0 && l == 0) atomicAdd(&ctr->errors, (unsigned long long)timeouts);
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
+    if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
+    if (kProbe && l == 0) {
+        atomicAdd(&ctr->probe[0], pr_eval); atomicAdd(&ctr->probe[1], pr_wait);
+        atomicAdd(&ctr->probe[2], pr_chain); atomicAdd(&ctr->probe[3], pr_check);
+        atomicAdd(&ctr->probe[4], pr_polls);
+        atomicAdd(&ctr->probe[5], (unsigned long long)((nturns - w + kW - 1) / kW));
+        if (wg == 0 && w == 0) {
+            ctr->probe[6] = __builtin_readcyclecounter() - pr_t0;   // shader clocks of one wave's life
+            ctr->probe[7] = wall_clock64() - pr_r0;                 // the same in 100 MHz ticks
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Force + collision + drift kernel, variant "ring", ROUND-1 form kept for A/B only (fp32): for own ranges with fewer chains than the chip has lanes.
+//
 // A workgroup of 8 waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
 // turns of 32 positions and the turns go round the waves: wave w takes turns w, w + 8, w + 16, ...  For its turn a
 // wave (1) loads the 95 tile entries its lanes need straight from the replica into a private LDS window (direct-to-LDS
@@ -904,7 +1293,7 @@ void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restr
 // ---------------------------------------------------------------------------------------------------------
 template <bool kLog>
 __global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
+void forces_ring_r1_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
                      Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
                      StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
     typedef float T;
@@ -1384,6 +1773,37 @@ __global__ __launch_bounds__(256) void render_discs(const Rec<T>* __restrict__ J
             const int x_sq = (x - xc) * (x - xc), y_sq = (y - yc) * (y - yc);
             if (x_sq + y_sq <= r2) img[(size_t)width * y + x] = 0;
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Device self-test of the assumption behind the ring kernel's hand-off: a 16-byte LDS record written by one lane
+// with ds_write_b128 is seen by a ds_read_b128 of another wave entirely old or entirely new.  Wave 0 of every
+// workgroup rewrites its 64 records {k, k, k, k} for k = 1..iters; the other seven waves poll them, count records
+// whose four words differ (torn) or whose k went backwards, and leave when they have seen k = iters.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(8 * kWave) void selftest_lds_record(unsigned long long* out, int iters) {
+    __shared__ Int4 rec[kWave];
+    const int l = threadIdx.x % kWave, w = threadIdx.x / kWave;
+    const LdsInt4Ptr mine = (LdsInt4Ptr)&rec[l];
+    if (w == 0) *mine = Int4{0, 0, 0, 0};
+    __syncthreads();
+    unsigned long long torn = 0, backwards = 0, reads = 0;
+    if (w == 0) {
+        for (int k = 1; k <= iters; ++k) *mine = Int4{k, k, k, k};
+    } else {
+        int last = 0;
+        for (long long guard = 0; guard < (1ll << 40); ++guard) {
+            const Int4 r = *mine;
+            ++reads;
+            torn += (r.x != r.y) || (r.y != r.z) || (r.z != r.w);
+            backwards += r.x < last;
+            last = r.x;
+            if (__ballot(r.x < iters) == 0ull) break;
+        }
+    }
+    if (torn) atomicAdd(&out[0], torn);
+    if (backwards) atomicAdd(&out[1], backwards);
+    if (reads) atomicAdd(&out[2], reads);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -42,6 +42,45 @@ def test_ieee_sqrt_and_reciprocal_exhaustive(nb):
     assert (m[0], m[1], m[2]) == (0, 0, 0)
 
 
+def test_lds_record_is_never_torn(nb):
+    """The ring kernel's hand-off assumption: a lane's 16-byte LDS record (ds_write_b128 / ds_read_b128) is seen
+    entirely old or entirely new by another wave.  512 workgroups x 64 records x 20000 rewrites, 7 polling waves."""
+    r = (ctypes.c_uint64 * 3)()
+    assert nb.lib.nbody_selftest_lds_record(0, 20000, ctypes.byref(r)) == 0, nb.lib.nbody_last_error_string()
+    assert r[0] == 0 and r[1] == 0, (r[0], r[1])
+    assert r[2] >= 512 * 7 * 64
+
+
+def test_ring_handoff_timeout_is_loud(nb, monkeypatch):
+    """A ring hand-off wait that gives up must not pass as a result (CUDA_SYNC_CHECK convention,
+    src/nbody.cu:20-33): with the poll limit shrunk to one poll some wave of the ring gives up, the kernel poisons
+    the chain, and every host entry point that looks at the device returns NBODY_ERR_HIP until the next upload."""
+    monkeypatch.setenv("NBODY_RING_SPIN_LIMIT", "1")
+    cfg = nb.stock_config(particleCount=16384, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg)
+    st = nb.Stepper(cfg, kernel_variant=50)
+    monkeypatch.delenv("NBODY_RING_SPIN_LIMIT")
+    st.upload(bodies)
+    st.step(2)
+    for call in (st.sync, st.download, st.stats, st.body_count, lambda: st.step(1),
+                 lambda: st.save_state("/tmp/never_written.nbody"), lambda: st.render_image(64, 64)):
+        with pytest.raises(nb.NbodyError) as e:
+            call()
+        assert e.value.status == -6 and "hand-off" in str(e.value), str(e.value)
+    assert not os.path.exists("/tmp/never_written.nbody")
+    # the poisoned state is visibly not a result; a fresh upload clears the failure but the limit stays
+    st.close()
+    ok = nb.Stepper(cfg, kernel_variant=50)              # default limit again
+    ok.upload(bodies)
+    ok.step(2)
+    one = nb.Stepper(cfg, kernel_variant=31)
+    one.upload(bodies)
+    one.step(2)
+    a, b = ok.download(), one.download()
+    assert a.numBodies == b.numBodies and np.array_equal(bits(a.block), bits(b.block))
+    ok.close(); one.close()
+
+
 def test_fp64_fast_chain_against_ieee(nb):
     """2^32 inputs of each of three families of the guarded domain: the fp64 force kernel's sqrt / 1/d^3 chain
     gives the bits of the compiler's correctly-rounded sqrt and divide (not exhaustive: fp64 cannot be)."""
@@ -55,7 +94,8 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40, 50]   # automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8 | ring
+# automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8 | ring and its tuning forms (sleep, 4 waves, 16-position turns)
+VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40, 50, 51, 52, 53]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
