@@ -235,11 +235,11 @@ inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bo
     else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-template <int kW, int kT, int kSleep, bool kProbe>
+template <int kW, int kT, int kSleep, bool kProbe, int kRings>
 void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
-    const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe>), dim3(grid), dim3(kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe>), dim3(grid), dim3(kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    const int grid = (nblocks * 2 + kRings - 1) / kRings;  // a workgroup serves kRings rings of 64 bodies, two per reference block
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 inline void launch_ring_r1(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = nblocks * 2;
@@ -261,11 +261,14 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
         case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
         case 40: launch_pc8(c, p, nblocks, log); return;
-        case 50: launch_ring<8, 32, 0, false>(c, p, nblocks, log); return;
-        case 51: launch_ring<8, 32, 1, false>(c, p, nblocks, log); return;      // tuning: s_sleep in the poll
-        case 52: launch_ring<4, 32, 0, false>(c, p, nblocks, log); return;      // tuning: 4 waves per ring
-        case 53: launch_ring<8, 16, 0, false>(c, p, nblocks, log); return;      // tuning: turns of 16 positions
-        case 58: launch_ring<8, 32, 0, true>(c, p, nblocks, log); return;       // tuning: in-kernel phase stamps
+        case 50: launch_ring<8, 32, 1, false, 2>(c, p, nblocks, log); return;   // 2 rings of 8 waves per workgroup
+        case 51: launch_ring<8, 32, 0, false, 2>(c, p, nblocks, log); return;   // tuning: no s_sleep in the poll
+        case 52: launch_ring<4, 32, 1, false, 4>(c, p, nblocks, log); return;   // 4 rings of 4 waves per workgroup
+        case 53: launch_ring<8, 16, 1, false, 2>(c, p, nblocks, log); return;   // tuning: turns of 16 positions
+        case 54: launch_ring<8, 32, 1, false, 1>(c, p, nblocks, log); return;   // tuning: one ring per workgroup
+        case 55: launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log); return;   // tuning: longer s_sleep
+        case 56: launch_ring<4, 32, 1, false, 2>(c, p, nblocks, log); return;   // tuning: 2 rings of 4 waves
+        case 58: launch_ring<8, 32, 1, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
         case 59: launch_ring_r1(c, p, nblocks, log); return;                    // round-1 form, A/B only
         default: break;
     }
@@ -275,7 +278,7 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //   >= 8k bodies   : ring of 8 waves per 64 bodies (11.6 vs 12.5 ms at 64k own bodies, 6.4 vs 7.1 ms at 32k)
     //   below          : 8-wave producer/consumer workgroups per 64 bodies
     if (c->own_upper >= 100000) launch_v3w<1, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 8192) launch_ring<8, 32, 0, false>(c, p, nblocks, log);
+    else if (c->own_upper >= 8192) launch_ring<8, 32, 1, false, 2>(c, p, nblocks, log);
     else launch_pc8(c, p, nblocks, log);
 }
 

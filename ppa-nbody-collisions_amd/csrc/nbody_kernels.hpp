@@ -930,19 +930,10 @@ __device__ __forceinline__ void load_to_lds_b128(const void* base, unsigned byte
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  ::"s"(lds_base), "v"(byte_offset), "s"(base) : "memory");
 }
-// One record from the replica WITHOUT the compiler knowing that a vector-memory operation happened: a tracked load
-// inside the turn loop makes hipcc guard later register writes and LDS reads with s_waitcnt vmcnt(0), which also
-// waits for the window prefetch.  Rare path (special tiles) only.
-__device__ __forceinline__ Rec<float> load_rec_untracked(const Rec<float>* src) {
-    typedef float Float4 __attribute__((ext_vector_type(4)));
-    Float4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(src) : "memory");
-    return Rec<float>{v.x, v.y, v.z, v.w};
-}
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
 
-template <bool kLog, int kW, int kT, int kSleep, bool kProbe>
-__global__ __launch_bounds__(kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings>
+__global__ __launch_bounds__(kRings * kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
                      Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
                      StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
@@ -953,19 +944,26 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     static_assert(kW % kTurnsPerTile == 0, "a wave's successive turns are whole tiles apart");
     constexpr int kTilesPerRound = kW / kTurnsPerTile;
     constexpr int kWin = kWave + kT;                       // window entries a turn can touch (kWin - 1 used)
-    __shared__ Rec<T> win[kW][2][kWin];                    // per wave, double buffered
-    __shared__ Int4 hand[kWave];                           // {fx, fy, seq, flags = version << 1 | deleted} per lane
-    __shared__ Float2 hand_m[kWave];                       // {mnew, rnew}, rewritten only when they change
+    static_assert(kRings == 1 || kRings == 2 || kRings == 4, "rings (64 bodies each) per workgroup");
+    __shared__ Rec<T> win_all[kRings][kW][2][kWin];        // per wave, double buffered
+    __shared__ Int4 hand_all[kRings][kWave];               // {fx, fy, seq, flags = version << 1 | deleted} per lane
+    __shared__ Float2 hand_m_all[kRings][kWave];           // {mnew, rnew}, rewritten only when they change
     const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
     const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int ring = wv / kW;                              // which 64 bodies of the block
+    const int w = wv % kW;                                 // place in the ring
     const int l = tid % kWave;
     const int wg = blockIdx.x;
-    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
-    const int t0 = (wg % 2) * kWave;
+    const int ring_g = wg * kRings + ring;                 // ring of the launch: two per reference block
+    const int half = ring_g % 2;
+    const int b = lo / kTile + ring_g / 2;                 // reference block
+    const int t0 = half * kWave;
     const int t = t0 + l;                                  // threadIdx.x of this lane's body in the reference
     const long long blk0 = (long long)b * kTile;
-    if (blk0 + t0 >= (long long)lo + cnt) return;
+    Rec<T>(&win)[kW][2][kWin] = win_all[ring];
+    Int4(&hand)[kWave] = hand_all[ring];
+    Float2(&hand_m)[kWave] = hand_m_all[ring];
     const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
     const bool lit = p.literal != 0;
     const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
@@ -993,8 +991,20 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     unsigned long long pairs = 0;
     const LdsInt4Ptr hand_l = (LdsInt4Ptr)&hand[l];
     const LdsFloat2Ptr hand_m_l = (LdsFloat2Ptr)&hand_m[l];
-    if (tid < kWave) *hand_l = Int4{0, 0, 0, 0};
+    if (w == 0) *hand_l = Int4{0, 0, 0, 0};
     __syncthreads();                                       // the only workgroup barrier: seq = 0 everywhere
+    if (blk0 + t0 >= (long long)lo + cnt) return;          // a ring without own bodies (after the barrier)
+    // Two rings share a CU's SIMDs (two per workgroup here, or two workgroups per CU), and the instruction arbiter
+    // serves the OLDER wave first at equal priority: left alone, the older ring runs at full speed, the younger one
+    // on what is left, and the CU then spends a third of the kernel with one ring only (measured: workgroups ended at
+    // 3.2 and 4.8 ms of a 4.8 ms launch, profiles/r02_ring_fairness.txt).  With both rings in one workgroup each
+    // wave compares the two chains' progress at the start of a turn and evaluates at priority 1 when its own ring is
+    // behind, 0 otherwise: the rings stay level and finish together.
+    typedef const volatile __attribute__((address_space(3))) int* LdsSeqPtr;
+    const LdsSeqPtr seq_mine = (LdsSeqPtr)&hand_all[ring][0] + 2;
+    const LdsSeqPtr seq_o1 = (LdsSeqPtr)&hand_all[(ring + 1) % kRings][0] + 2;    // the other rings of the workgroup
+    const LdsSeqPtr seq_o2 = (LdsSeqPtr)&hand_all[(ring + 2) % kRings][0] + 2;
+    const LdsSeqPtr seq_o3 = (LdsSeqPtr)&hand_all[(ring + 3) % kRings][0] + 2;
     unsigned long long pr_eval = 0, pr_wait = 0, pr_chain = 0, pr_check = 0, pr_polls = 0, pr_t0 = 0, pr_r0 = 0;
     if (kProbe) { pr_t0 = __builtin_readcyclecounter(); pr_r0 = wall_clock64(); }
 
@@ -1014,13 +1024,19 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         if (lit) return (kk == nb - 1) ? N % (kTile + 1) : kTile;             // :194 (quirk Q1)
         return (N - st) < kTile ? (int)(N - st) : kTile;
     };
-    // is every position of tile kk an ordinary pair for every lane of the workgroup?
-    auto interior = [&](int kk, long long st) -> bool {
-        return lit ? (kk >= 1 && kk <= nb - 2) : (tile_len(kk, st) == kTile && kk != b);
+    // Every turn reads its tile entries from the wave's LDS window, never from the replica.  Kind of a turn's window:
+    // 0 none (past the walk), 1 the standard window of a full tile, 2 a truncated tile (literal: the last one, of
+    // N mod 129 entries; clean: the partial last one), held whole.
+    auto turn_kind = [&](int tau, long long st) -> int {
+        if (tau >= nturns) return 0;
+        return tile_len(tau / kTurnsPerTile, st) == kTile ? 1 : 2;
     };
-    // The window of a fast turn: entry j of the window is tile entry (wbase0 + off0 + j) mod 128, and off0 is the same
+    // may a full tile take the fast path?  literal: yes (the self position, tile 0 / walk position 0, is masked in the
+    // first turn); clean: not the tile that holds the workgroup's own bodies (the self position differs per lane)
+    auto fast_tile = [&](int kk) -> bool { return lit || kk != b; };
+    // The standard window: entry j of the window is tile entry (wbase0 + off0 + j) mod 128, and off0 is the same
     // for every turn of a wave (kW is a multiple of the turns per tile): the tile entries this lane fetches are two
-    // per-lane constants, the body index is that plus the tile's first body, wrapped once (interior tiles: N >= 384).
+    // per-lane constants, the body index is that plus the tile's first body, wrapped at most once (st < N, e < 128 <= N).
     const int wbase0 = lit ? t0 : 0;                       // literal: lane l reads window[l + r]; clean: window[r]
     const int nwin = lit ? (kWave + kT - 1) : kT;          // entries of the window that are used
     const unsigned e0 = (unsigned)(wbase0 + (w % kTurnsPerTile) * kT + l) & (kTile - 1);
@@ -1030,22 +1046,26 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const unsigned wrapped = src - (unsigned)N;        // huge when src < N
         return (src < wrapped ? src : wrapped) * (unsigned)sizeof(Rec<T>);
     };
-    // The window of turn tau, loaded from the replica STRAIGHT INTO LDS (lane l's 16 bytes land at base + 16 l), so
-    // the prefetch holds no registers and stays in flight for a whole turn.  Returns whether the turn can take
-    // the fast path as far as is known before the data has arrived.
-    auto issue_window = [&](int tau, long long st, int buf) -> bool {
-        if (tau >= nturns) return false;
-        const int kk = tau / kTurnsPerTile;
-        if (!(interior(kk, st) && wave_ok)) return false;
+    // Loaded from the replica STRAIGHT INTO LDS (lane l's 16 bytes land at base + 16 l): the prefetch holds no
+    // registers and stays in flight for a whole turn.
+    auto issue_window = [&](long long st, int buf) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0]));
         if (l < nwin) load_to_lds_b128(J, window_offset(st, e0), base);
         if (l + kWave < nwin) load_to_lds_b128(J, window_offset(st, e1), base + kWave * (unsigned)sizeof(Rec<T>));
-        return true;
+    };
+    // A truncated tile: its L <= 128 entries in order, across BOTH window buffers (2 * kWin >= 128 records), so it
+    // can only be issued when the wave is done with its current window: after the hand-off of the turn before.
+    static_assert(2 * kWin >= kTile, "a whole tile fits the two window buffers");
+    Rec<T>* const whole = &win[w][0][0];
+    auto issue_truncated = [&](long long st, int L) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(whole));
+        if (l < L) load_to_lds_b128(J, window_offset(st, (unsigned)l), base);
+        if (l + kWave < L) load_to_lds_b128(J, window_offset(st, (unsigned)(l + kWave)), base + kWave * (unsigned)sizeof(Rec<T>));
     };
     // after the loads have landed: are all coordinates of the window bounded, is some radius not +0.0f
     struct WindowState { bool fast, rnz; };
-    auto check_window = [&](bool issued, int buf) -> WindowState {
-        if (!issued) return WindowState{false, true};
+    auto check_window = [&](int kind, int kk, int buf) -> WindowState {
+        if (kind != 1) return WindowState{false, true};    // (a truncated tile is waited for where it is read)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // issued a whole turn ago
         __builtin_amdgcn_wave_barrier();
         Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
@@ -1054,25 +1074,35 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const bool bad0 = !((abs_(r0.x) < kCoordBound) && (abs_(r0.y) < kCoordBound));
         const bool bad1 = !((abs_(r1.x) < kCoordBound) && (abs_(r1.y) < kCoordBound));
         WindowState ws;
-        ws.fast = __ballot(bad0 || bad1) == 0ull;
+        ws.fast = __ballot(bad0 || bad1) == 0ull && wave_ok && fast_tile(kk);
         // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
         ws.rnz = __ballot(not_plus_zero(r0.r) || not_plus_zero(r1.r)) != 0ull;
         return ws;
     };
-    // one walk position by the general code, record fetched from the replica
-    auto general_at = [&](int kk, long long st, int L, int off) {
-        int sidx;
-        long long j;
-        if (lit) {
-            if (kk == 0 && off == 0) return;                                   // :200-204
-            sidx = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L); // :207
-            j = st + sidx;
-            if (j >= N) j %= N;
-        } else {
-            j = st + off;
-            if (j == i64) return;
+    // the general code on this turn's walk positions, records from the window (kind 1) / the whole tile (kind 2)
+    auto general_turn = [&](int kind, int kk, long long st, int L, int off0, int buf) {
+        if (kind == 2) {                                   // issued after the previous own turn's hand-off
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
-        interact<T, kLog>(a, load_rec_untracked(J + j), p.growth, i, (int)j, ev, ev_cap, ctr, step);
+        const int hi = off0 + kT < L ? off0 + kT : L;
+#pragma unroll 1
+        for (int off = off0; off < hi; ++off) {
+            int sidx;
+            long long j;
+            if (lit) {
+                if (kk == 0 && off == 0) continue;                                 // :200-204
+                sidx = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L); // :207
+                j = st + sidx;
+                if (j >= N) j %= N;
+            } else {
+                sidx = off;
+                j = st + off;
+                if (j == i64) continue;
+            }
+            const Rec<T> rec = kind == 1 ? win[w][buf][(lit ? l : 0) + (off - off0)] : whole[sidx];
+            interact<T, kLog>(a, rec, p.growth, i, (int)j, ev, ev_cap, ctr, step);
+        }
     };
 
     long long st = tile_start_slow(w / kTurnsPerTile);
@@ -1088,7 +1118,10 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             mver = flags_in >> 1;
         }
     };
-    WindowState cur = check_window(issue_window(w, st, buf), buf);
+    int kind = turn_kind(w, st);
+    if (kind == 1) issue_window(st, buf);
+    if (kind == 2) issue_truncated(st, tile_len(w / kTurnsPerTile, st));
+    WindowState cur = check_window(kind, w / kTurnsPerTile, buf);
     for (int tau = w; tau < nturns; tau += kW) {
         unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
         if (kProbe) pt0 = __builtin_readcyclecounter();
@@ -1097,7 +1130,19 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const int L = tile_len(kk, st);
         const bool fast = cur.fast;
         const long long st_next = round_on(st);
-        const bool issued_next = issue_window(tau + kW, st_next, buf ^ 1);   // in flight for the whole turn
+        const int kind_next = turn_kind(tau + kW, st_next);
+        if (kind_next == 1) issue_window(st_next, buf ^ 1);                  // in flight for the whole turn
+        const bool first = lit && tau == 0;                // walk position 0 is the body itself (:200-204)
+        if (kRings > 1) {                                  // behind the furthest ring of the workgroup: evaluate first
+            int ahead = *seq_o1;
+            if (kRings == 4) {
+                const int o2 = *seq_o2, o3 = *seq_o3;
+                ahead = ahead > o2 ? ahead : o2;
+                ahead = ahead > o3 ? ahead : o3;
+            }
+            if (*seq_mine < ahead) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         // (2) the kT terms of this turn
         V2 term[kT];
         unsigned long long flag = 0;
@@ -1131,7 +1176,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                             rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
                             q = __builtin_elementwise_fma(rs, rs, q);          // flag only
                         }
-                        flag |= le_mask(d2.x, q.x);
+                        const unsigned long long close_a = le_mask(d2.x, q.x);
+                        flag |= (r0 + u == 0 && first) ? 0ull : close_a;
                         flag |= le_mask(d2.y, q.y);
                         const V2 inv = fast_inv_cube2(d2);
                         term[r0 + u] = (da * ba.m) * inv.x;
@@ -1141,6 +1187,9 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             };
             if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
             else evaluate(std::false_type{});
+            // the reference skips the self position; the sum starts at +0.0f and +0 + +0 = +0: adding a zero term is
+            // the same bits (whatever the self "pair" evaluated to is dropped here)
+            if (first) term[0] = V2{0.0f, 0.0f};
         }
         if (kProbe) pt1 = __builtin_readcyclecounter();
         // (3) the state after turn tau - 1.  Polled at raised priority: a poll is one LDS read plus scalar work, it
@@ -1178,7 +1227,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, flags_in};
             __builtin_amdgcn_s_setprio(0);
             a.fx = fx; a.fy = fy;
-            if (active) pairs += kT;
+            if (active) pairs += kT - (first ? 1 : 0);
         } else {
             a.fx = __int_as_float(h.x); a.fy = __int_as_float(h.y);
             sync_rare();
@@ -1188,14 +1237,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             if (fast) {
                 if (active) {
                     if ((flag >> l) & 1ull) {
-#pragma unroll 1
-                        for (int r = 0; r < kT; ++r) {
-                            const int off = off0 + r;
-                            const int sidx = lit ? ((t + off) & (kTile - 1)) : off;
-                            long long j = st + sidx;
-                            if (j >= N) j -= N;
-                            interact<T, kLog>(a, win[w][buf][(lit ? l : 0) + r], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-                        }
+                        general_turn(1, kk, st, L, off0, buf);
                     } else {
                         float fx = a.fx, fy = a.fy;
 #pragma unroll
@@ -1205,11 +1247,11 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                         }
                         a.fx = fx; a.fy = fy;
                     }
-                    pairs += kT;
+                    pairs += kT - (first ? 1 : 0);
                 }
             } else if (active) {
+                general_turn(kind, kk, st, L, off0, buf);
                 const int hi = off0 + kT < L ? off0 + kT : L;
-                for (int off = off0; off < hi; ++off) general_at(kk, st, L, off);
                 if (lit) {
                     if (hi > off0) pairs += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
                 } else {
@@ -1233,9 +1275,11 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         }
         if (kProbe) pt3 = __builtin_readcyclecounter();
         // the prefetched window of this wave's next turn
+        if (kind_next == 2) issue_truncated(st_next, tile_len((tau + kW) / kTurnsPerTile, st_next));   // both buffers are free now
         buf ^= 1;
         st = st_next;
-        cur = check_window(issued_next, buf);
+        kind = kind_next;
+        cur = check_window(kind, (tau + kW) / kTurnsPerTile, buf);
         if (kProbe) {
             pr_eval += pt1 - pt0; pr_wait += pt2 - pt1; pr_chain += pt3 - pt2;
             pr_check += __builtin_readcyclecounter() - pt3;
@@ -1269,6 +1313,13 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         if (wg == 0 && w == 0) {
             ctr->probe[6] = __builtin_readcyclecounter() - pr_t0;   // shader clocks of one wave's life
             ctr->probe[7] = wall_clock64() - pr_r0;                 // the same in 100 MHz ticks
+        }
+        if (w == 0) {   // where and when this workgroup ran: {start, end (constant-rate ticks), HW_ID, XCC_ID << 20 | wg}
+            const unsigned long long slot = atomicAdd(&ctr->events, 1ull);
+            if (slot < (unsigned long long)ev_cap)
+                ev[slot] = Event{(int)(unsigned)pr_r0, (int)(unsigned)wall_clock64(),
+                                 (int)__builtin_amdgcn_s_getreg((31 << 11) | 4),
+                                 (int)((__builtin_amdgcn_s_getreg((31 << 11) | 20) << 20) | (unsigned)wg)};
         }
     }
 }

@@ -45,4 +45,26 @@ for variant in variants:
         print("   probe rank0: per wave-turn cycles: evaluate %.0f  wait %.0f  chain+publish %.0f  check %.0f;"
               " polls/turn %.2f; shader clock %.2f GHz (one wave's life %.3f ms)" %
               (p[0] / turns, p[1] / turns, p[2] / turns, p[3] / turns, p[4] / turns, ghz, p[7] / 1e5), flush=True)
+        ev = grp.ranks[0].events()
+        if len(ev):
+            t0 = ev["step"].astype(np.int64) & 0xffffffff
+            t1 = ev["i"].astype(np.int64) & 0xffffffff
+            base = t0.min()
+            hw = ev["j"].astype(np.int64) & 0xffffffff
+            xcc = (ev["kind"].astype(np.int64) >> 20) & 0xf
+            cu = (hw >> 8) & 0xf
+            se = (hw >> 13) & 0x7
+            place = xcc * 1000 + se * 100 + cu
+            print("   %d workgroup records (all launches); start ticks after first: p50 %d p90 %d max %d; "
+                  "life ticks: min %d p50 %d max %d; distinct (xcc,se,cu): %d; max WGs on one CU: %d" %
+                  (len(ev), np.percentile(t0 - base, 50), np.percentile(t0 - base, 90), (t0 - base).max(),
+                   (t1 - t0).min(), np.percentile(t1 - t0, 50), (t1 - t0).max(), len(np.unique(place)),
+                   np.bincount(np.unique(place, return_inverse=True)[1]).max()))
+            last = ev[-min(len(ev), 512):]
+            lt0 = (last["step"].astype(np.int64) & 0xffffffff); lt1 = (last["i"].astype(np.int64) & 0xffffffff)
+            lb = lt0.min()
+            print("   last launch: starts p50 %d p99 %d max %d; ends min %d p50 %d max %d (ticks after its first start)" %
+                  (np.percentile(lt0 - lb, 50), np.percentile(lt0 - lb, 99), (lt0 - lb).max(), (lt1 - lb).min(),
+                   np.percentile(lt1 - lb, 50), (lt1 - lb).max()))
+            np.save("gpurun_out/r02_ring_wg_records_N%d_G%d.npy" % (n, world), ev)
     grp.close()

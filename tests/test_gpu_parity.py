@@ -95,7 +95,7 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
 
 
 # automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8 | ring and its tuning forms (sleep, 4 waves, 16-position turns)
-VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40, 50, 51, 52, 53]
+VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40, 50, 51, 52, 53, 54, 55, 56]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
