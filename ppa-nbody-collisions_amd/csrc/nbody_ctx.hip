@@ -11,6 +11,7 @@
 // sharding unchanged.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -143,6 +144,9 @@ int ring_spin_limit() {                                    // read when a contex
     return v > 0 && v < (1l << 30) ? (int)v : (1 << 24);
 }
 
+inline bool not_plus_zero_host(float x) { uint32_t u; memcpy(&u, &x, 4); return u != 0; }
+inline bool not_plus_zero_host(double x) { uint64_t u; memcpy(&u, &x, 8); return u != 0; }
+
 template <typename T>
 StepParams<T> make_params(const nbody_ctx_desc& d, int spin_limit = 1 << 24) {
     StepParams<T> p;
@@ -235,11 +239,11 @@ inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bo
     else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-template <int kW, int kT, int kSleep, bool kProbe, int kRings>
+template <int kW, int kT, int kSleep, bool kProbe, int kRings, int kExp = 0>
 void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = (nblocks * 2 + kRings - 1) / kRings;  // a workgroup serves kRings rings of 64 bodies, two per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings, kExp>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings, kExp>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
 inline void launch_ring_r1(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = nblocks * 2;
@@ -268,18 +272,22 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 54: launch_ring<8, 32, 1, false, 1>(c, p, nblocks, log); return;   // tuning: one ring per workgroup
         case 55: launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log); return;   // tuning: longer s_sleep
         case 56: launch_ring<4, 32, 1, false, 2>(c, p, nblocks, log); return;   // tuning: 2 rings of 4 waves
+        case 63: launch_ring<4, 32, 2, false, 4, 0>(c, p, nblocks, log); return;   // tuning: s_sleep 2
         case 58: launch_ring<8, 32, 1, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
         case 59: launch_ring_r1(c, p, nblocks, log); return;                    // round-1 form, A/B only
         default: break;
     }
-    // default: chosen by how many bodies this rank owns, i.e. how many chains there are to fill the chip with
-    // (measured on MI355X with csrc/tune/scaling_probe.py at N=262144 and bench.py at smaller N, profiles/):
-    //   >= 100k bodies : one lane per body, 256-thread workgroups, registers sized for 4 waves per SIMD
-    //   >= 8k bodies   : ring of 8 waves per 64 bodies (11.6 vs 12.5 ms at 64k own bodies, 6.4 vs 7.1 ms at 32k)
-    //   below          : 8-wave producer/consumer workgroups per 64 bodies
-    if (c->own_upper >= 100000) launch_v3w<1, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 8192) launch_ring<8, 32, 1, false, 2>(c, p, nblocks, log);
-    else launch_pc8(c, p, nblocks, log);
+    // default: chosen by how many bodies this rank owns, i.e. how many ordered chains there are to fill the chip with
+    // (measured on MI355X with csrc/tune/ring_probe.py, profiles/r02_ring_*):
+    //   >= 48k bodies : ring kernel, workgroups of 4 rings x 4 waves (256 bodies): 32.2 ms at 262144 own bodies
+    //                   (one lane per body: 33.6), 16.6 / 8.4 ms at 131072 / 65536 (18.5 / 10.2)
+    //   >= 24k bodies : ring kernel, workgroups of 2 rings x 8 waves (128 bodies): fills the chip with half the bodies
+    //                   (4.35 ms at 32768 own bodies of 262144; 4 x 4: 5.4)
+    //   below         : ring kernel, one ring of 8 waves per workgroup: twice the workgroups to spread over the CUs
+    //                   (0.21 ms at N = 16384; 2 x 8: 0.29; the producer/consumer kernel of round 1: 0.31)
+    if (c->own_upper >= 49152) launch_ring<4, 32, 1, false, 4>(c, p, nblocks, log);
+    else if (c->own_upper >= 24576) launch_ring<8, 32, 1, false, 2>(c, p, nblocks, log);
+    else launch_ring<8, 32, 1, false, 1>(c, p, nblocks, log);
 }
 
 template <typename T>
@@ -499,14 +507,19 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     const int lo = (int)((long long)n * g / G), hi = (int)((long long)n * (g + 1) / G);
     const int cnt = hi - lo;
     if (cnt > c->cap_own) return nbody_fail(NBODY_ERR_CAPACITY, "own range %d > own capacity %d", cnt, c->cap_own);
-    // pack [P|V|M|R] (src/nbody.cu:66-77) into {x,y,m,r} records
+    // pack [P|V|M|R] (src/nbody.cu:66-77) into {x,y,m,r} records; Meta::summary as unpack_slots computes it per step
+    int summary = 0;
     if (c->desc.precision == NBODY_F64) {
         const double* P = (const double*)block;
         const double* V = P + 2 * (size_t)n;
         const double* M = V + 2 * (size_t)n;
         const double* R = M + (size_t)n;
         Rec<double>* st = (Rec<double>*)c->h_stage;
-        for (int i = 0; i < n; ++i) st[i] = Rec<double>{P[2 * i], P[2 * i + 1], M[i], R[i]};
+        for (int i = 0; i < n; ++i) {
+            st[i] = Rec<double>{P[2 * i], P[2 * i + 1], M[i], R[i]};
+            const bool bounded = fabs(st[i].x) < FastDomain<double>::coord && fabs(st[i].y) < FastDomain<double>::coord;
+            summary |= (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero_host(R[i]) ? kSummaryRadius : 0);
+        }
         HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<double>), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 16, hipMemcpyHostToDevice, c->stream));
     } else {
@@ -515,11 +528,16 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
         const float* M = V + 2 * (size_t)n;
         const float* R = M + (size_t)n;
         Rec<float>* st = (Rec<float>*)c->h_stage;
-        for (int i = 0; i < n; ++i) st[i] = Rec<float>{P[2 * i], P[2 * i + 1], M[i], R[i]};
+        for (int i = 0; i < n; ++i) {
+            st[i] = Rec<float>{P[2 * i], P[2 * i + 1], M[i], R[i]};
+            const bool bounded = fabsf(st[i].x) < FastDomain<float>::coord && fabsf(st[i].y) < FastDomain<float>::coord;
+            summary |= (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero_host(R[i]) ? kSummaryRadius : 0);
+        }
         HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<float>), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
     }
     c->h_meta->n = n; c->h_meta->lo = lo; c->h_meta->cnt = cnt; c->h_meta->step = 0; c->h_meta->n_prev = n;
+    c->h_meta->summary = summary; c->h_meta->pad[0] = c->h_meta->pad[1] = 0;
     *c->h_meta_async = *c->h_meta;
     HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));

@@ -39,8 +39,11 @@ struct Meta {
     int cnt;      // number of bodies owned by this rank
     int step;     // step counter since upload
     int n_prev;   // body count before the last step's compaction (the reference renders with its block count)
-    int pad[3];
+    int summary;  // of the replica: bit 0 some coordinate is not below kCoordBound in magnitude (or NaN), bit 1 some
+                  // radius is not +0.  OR-ed together by unpack_slots (cleared by compact_count), set by nbody_upload.
+    int pad[2];
 };
+constexpr int kSummaryUnbounded = 1, kSummaryRadius = 2;
 
 struct Event { int32_t step, i, j, kind; };
 
@@ -932,7 +935,7 @@ __device__ __forceinline__ void load_to_lds_b128(const void* base, unsigned byte
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
 
-template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings>
+template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings, int kExp = 0>
 __global__ __launch_bounds__(kRings * kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
                      Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
@@ -949,6 +952,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     __shared__ Int4 hand_all[kRings][kWave];               // {fx, fy, seq, flags = version << 1 | deleted} per lane
     __shared__ Float2 hand_m_all[kRings][kWave];           // {mnew, rnew}, rewritten only when they change
     const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    const bool all_bounded = (meta->summary & kSummaryUnbounded) == 0, any_radius = (meta->summary & kSummaryRadius) != 0;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int ring = wv / kW;                              // which 64 bodies of the block
@@ -1068,6 +1072,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         if (kind != 1) return WindowState{false, true};    // (a truncated tile is waited for where it is read)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // issued a whole turn ago
         __builtin_amdgcn_wave_barrier();
+        // the whole replica is bounded (Meta::summary): no scan of the window; all its radii are +0 or not, globally
+        if (all_bounded) return WindowState{wave_ok && fast_tile(kk), any_radius};
         Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
         if (l < nwin) r0 = win[w][buf][l];
         if (l + kWave < nwin) r1 = win[w][buf][l + kWave];
@@ -1157,7 +1163,10 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 for (int r0 = 0; r0 < kT; r0 += kG) {
                     Rec<T> rec[kG];
 #pragma unroll
-                    for (int u = 0; u < kG; ++u) rec[u] = walk[r0 + u];
+                    for (int u = 0; u < kG; ++u) {
+                        rec[u] = walk[r0 + u];
+                        if (kExp & 2) asm volatile("" : "+v"(rec[u].x), "+v"(rec[u].y), "+v"(rec[u].m), "+v"(rec[u].r));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < kG; u += 2) {
@@ -1617,6 +1626,7 @@ __global__ __launch_bounds__(kCompactBlock) void compact_count(const Rec<T>* __r
     __shared__ int wsum[kCompactBlock / kWave];
     const int cnt = meta->cnt;
     const int q = blockIdx.x * kCompactBlock + threadIdx.x;
+    if (q == 0) const_cast<Meta*>(meta)->summary = 0;      // the force kernel of this step is done with it
     const bool keep = q < cnt && S_J[q].m != (T)0;
     const unsigned long long bal = __ballot(keep);
     if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = __popcll(bal);
@@ -1699,7 +1709,16 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
     const int c = reinterpret_cast<const SlotHeader*>(slot)->count;
     const Rec<T>* recs = reinterpret_cast<const Rec<T>*>(slot + sizeof(SlotHeader));
     const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q < c) J[off + q] = recs[q];
+    int bits = 0;
+    if (q < c) {
+        const Rec<T> r = recs[q];
+        J[off + q] = r;
+        const bool bounded = abs_(r.x) < FastDomain<T>::coord && abs_(r.y) < FastDomain<T>::coord;
+        bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
+    }
+    const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
+                          (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0);
+    if (wave_bits != 0 && (threadIdx.x & (kWave - 1)) == 0) atomicOr(&meta->summary, wave_bits);
     if (g == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         // every block has read meta-independent data only, so the in-place update is race-free
         const int step = meta->step;

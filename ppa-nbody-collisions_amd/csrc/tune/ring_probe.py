@@ -38,6 +38,8 @@ for variant in variants:
         same = "  bits==first: %s" % np.array_equal(ref.view(np.uint32), out.block.view(np.uint32))
     print("N=%d G=%d variant=%2d  kernel ms/rank: max %.3f min %.3f  -> %.3e pairs/s%s" %
           (n, world, variant, max(ms), min(ms), pairs / (max(ms) * 1e-3), same), flush=True)
+    if max(ms) > 1.1 * min(ms):
+        print("   per rank:", " ".join("%.3f" % m for m in ms), flush=True)
     if variant == 58:
         p = grp.ranks[0].ring_probe()
         turns = max(1, p[5])
