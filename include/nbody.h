@@ -232,6 +232,11 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps);
 int nbody_group_download(nbody_ctx** ctxs, int world, void* block, int* n);
 /* Global index range [lo, lo+cnt) currently owned by this rank (synchronises). */
 int nbody_own_range(nbody_ctx* ctx, int* lo, int* cnt);
+/* The partition rule itself (pure host function, no device needed): whole reference blocks of 128 bodies
+ * (THREADS_PER_BLOCK, src/nbody.cu:36), as evenly as the block count allows, in rank order.  nbody_upload draws it
+ * for the uploaded count and the device re-draws it from the survivor count after every step, so ranks stay level
+ * as bodies are deleted (the reference's compaction is global, src/nbody.cu:488-510). */
+int nbody_partition(int n, int rank, int world, int* lo, int* cnt);
 void* nbody_ctx_stream(nbody_ctx* ctx);   /* hipStream_t of the context */
 
 /* ---------------------------------------------------------------------------------------------------
@@ -265,6 +270,11 @@ int nbody_selftest_chain_f64(int device, uint64_t inputs_per_mode, uint64_t mism
  * records `iters` times while seven waves poll them.  result = {torn records seen, sequence numbers going
  * backwards, records read}; the first two must be 0. */
 int nbody_selftest_lds_record(int device, int iters, uint64_t result[3]);
+
+/* Profiling aid: launches ONLY the force kernel of the context's current state `reps` times, back to back; the
+ * results land in the staging buffers and are never committed, so the state does not change (the pair and event
+ * counters do count).  Lets one rank's kernel of a G-rank partition be timed / profiled in steady state on one GPU. */
+int nbody_debug_force_only(nbody_ctx* ctx, int reps);
 
 /* Tuning aid (kernel_variant 58 only): cycle totals of the ring kernel's phases since upload, summed over waves:
  * {evaluate, wait, chain+publish, window check, polls, turns, shader clocks of one wave's life, the same in 100 MHz

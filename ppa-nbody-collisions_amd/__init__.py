@@ -118,6 +118,7 @@ SYMBOLS = {
     "nbody_group_step": (_i, [_pp, _i, _i]),
     "nbody_group_download": (_i, [_pp, _i, _vp, _ip]),
     "nbody_own_range": (_i, [_vp, _ip, _ip]),
+    "nbody_partition": (_i, [_i, _i, _i, _ip, _ip]),
     "nbody_ctx_stream": (_vp, [_vp]),
     "nbody_num_blocks": (_i, [_i]),
     "nbody_launch_compute_forces_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _i, _i, _f, _vp]),
@@ -126,6 +127,7 @@ SYMBOLS = {
     "nbody_selftest_chain_f64": (_i, [_i, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64 * 2)]),
     "nbody_selftest_lds_record": (_i, [_i, _i, ctypes.POINTER(ctypes.c_uint64 * 3)]),
     "nbody_debug_ring_probe": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64 * 8)]),
+    "nbody_debug_force_only": (_i, [_vp, _i]),
 }
 
 
@@ -270,6 +272,13 @@ def saveImageToDisk(filename, img):
     _check(lib.nbody_write_pgm(os.fsencode(filename), img.ctypes.data, img.shape[1], img.shape[0]))
 
 
+def partition(n, rank, world):
+    """(lo, cnt) of rank's own range when n bodies are partitioned over world ranks (nbody_partition)."""
+    lo, cnt = ctypes.c_int(0), ctypes.c_int(0)
+    _check(lib.nbody_partition(n, rank, world, ctypes.byref(lo), ctypes.byref(cnt)))
+    return lo.value, cnt.value
+
+
 def comm_unique_id():
     buf = ctypes.create_string_buffer(COMM_ID_BYTES)
     _check(lib.nbody_comm_unique_id(buf))
@@ -370,6 +379,9 @@ class Stepper:
 
     def set_kernel_timing(self, enable=True):
         _check(lib.nbody_set_kernel_timing(self._ctx, int(enable)))
+
+    def force_only(self, reps):
+        _check(lib.nbody_debug_force_only(self._ctx, reps))
 
     def ring_probe(self):
         out = (ctypes.c_uint64 * 8)()

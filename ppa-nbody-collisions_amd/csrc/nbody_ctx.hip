@@ -179,6 +179,13 @@ int resolve_timing(nbody_ctx* c) {
 // The convention of CUDA_SYNC_CHECK (src/nbody.cu:20-33): a failure on the device surfaces at the next point where
 // the host looks.  The only in-kernel failure is a ring hand-off wait that gave up (the kernel then poisons its
 // output with NaNs); once seen it is sticky until the next nbody_upload.
+// Upper bound of any rank's own count when the body count is at most n: the partition is re-drawn every step, a
+// rank's range can grow by a block while the total shrinks, but never beyond ceil(blocks / world) blocks.
+int own_upper_of(const nbody_ctx* c, int n) {
+    const long long blocks = ((long long)n + kTile - 1) / kTile;
+    return (int)((blocks + c->desc.world - 1) / c->desc.world) * kTile;
+}
+
 int device_failure(nbody_ctx* c, unsigned long long errors) {
     if (errors != 0) c->device_failed = true;
     if (!c->device_failed) return NBODY_OK;
@@ -192,7 +199,7 @@ int read_meta(nbody_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->h_counters, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_upper = c->h_meta->n;
-    c->own_upper = c->h_meta->cnt;
+    c->own_upper = own_upper_of(c, c->n_upper);
     return device_failure(c, c->h_counters->errors);
 }
 
@@ -291,18 +298,7 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
 }
 
 template <typename T>
-int launch_compute(nbody_ctx* c) {
-    const StepParams<T> p = make_params<T>(c->desc, c->spin_limit);
-    {
-        const int cnt_seen = *(volatile int*)&c->h_meta_async->cnt, n_seen = *(volatile int*)&c->h_meta_async->n;
-        if (cnt_seen > 0 && cnt_seen < c->own_upper) c->own_upper = cnt_seen;
-        if (n_seen > 0 && n_seen < c->n_upper) c->n_upper = n_seen;
-    }
-    // Workgroups cover every reference block that can intersect the own range: a range of cnt bodies
-    // touches at most cnt/128 + 2 blocks wherever it starts.  The count only shrinks between syncs, so the
-    // host-side upper bound is safe; the kernel takes the exact range from the device-side Meta and
-    // workgroups past it exit at once.
-    const int nblocks = c->own_upper / kTile + 2;
+int launch_force_kernel(nbody_ctx* c, const StepParams<T>& p, int nblocks) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->timing) {
         HIP_TRY(hipEventCreate(&e0));
@@ -317,6 +313,22 @@ int launch_compute(nbody_ctx* c) {
         c->ev_pool.push_back(e0);
         c->ev_pool.push_back(e1);
     }
+    return NBODY_OK;
+}
+
+template <typename T>
+int launch_compute(nbody_ctx* c) {
+    const StepParams<T> p = make_params<T>(c->desc, c->spin_limit);
+    {
+        const int n_seen = *(volatile int*)&c->h_meta_async->n;
+        if (n_seen > 0 && n_seen < c->n_upper) { c->n_upper = n_seen; c->own_upper = own_upper_of(c, n_seen); }
+    }
+    // Workgroups cover every reference block of the own range, which starts on a block boundary (own_range_of).  The
+    // body count only shrinks between syncs, so the host-side upper bound is safe; the kernel takes the exact range
+    // from the device-side Meta and workgroups past it exit at once.
+    const int nblocks = c->own_upper / kTile > 0 ? c->own_upper / kTile : 1;
+    int rc = launch_force_kernel<T>(c, p, nblocks);
+    if (rc != NBODY_OK) return rc;
     const int nblk = (c->own_upper + kCompactBlock - 1) / kCompactBlock > 0
                          ? (c->own_upper + kCompactBlock - 1) / kCompactBlock : 1;
     hipLaunchKernelGGL((compact_count<T>), dim3(nblk), dim3(kCompactBlock), 0, c->stream,
@@ -324,7 +336,8 @@ int launch_compute(nbody_ctx* c) {
     hipLaunchKernelGGL((compact_scatter<T>), dim3(nblk), dim3(kCompactBlock), 0, c->stream,
                        (const Rec<T>*)c->S_J, (const Vec2<T>*)c->S_V, (const Meta*)c->meta,
                        (const int*)c->blk_counts, nblk, (SlotHeader*)c->slot,
-                       (Rec<T>*)(c->slot + sizeof(SlotHeader)), (Vec2<T>*)c->Vown);
+                       (Rec<T>*)(c->slot + sizeof(SlotHeader)),
+                       (Vec2<T>*)(c->slot + sizeof(SlotHeader) + (size_t)c->cap_own * sizeof(Rec<T>)));
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
@@ -336,8 +349,8 @@ int launch_commit(nbody_ctx* c) {
     // grid by the largest count any rank can have
     const int gx_all = c->desc.world > 1 ? (c->cap_own + 255) / 256 : gx;
     hipLaunchKernelGGL((unpack_slots<T>), dim3(gx_all, c->desc.world), dim3(256), 0, c->stream,
-                       (const unsigned char*)c->gather, c->slot_bytes, c->desc.world, c->desc.rank,
-                       (Rec<T>*)c->J, c->meta);
+                       (const unsigned char*)c->gather, c->slot_bytes, c->cap_own, c->desc.world, c->desc.rank,
+                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
@@ -397,6 +410,13 @@ int nbody_comm_unique_id(void* out128) {
     return NBODY_OK;
 }
 
+int nbody_partition(int n, int rank, int world, int* lo, int* cnt) {
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !cnt)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_partition: bad argument");
+    own_range_of(n, rank, world, lo, cnt);
+    return NBODY_OK;
+}
+
 int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     if (!out || !d) return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: NULL argument");
     *out = nullptr;
@@ -429,9 +449,12 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     c->real_bytes = d->precision == NBODY_F64 ? 8 : 4;
     c->rec_bytes = 4 * c->real_bytes;
     c->cap = d->capacity;
-    c->cap_own = (int)(((long long)d->capacity + d->world - 1) / d->world) + 1;
+    {   // largest own range of the block-aligned partition (own_range_of): ceil(blocks / world) reference blocks
+        const long long blocks = ((long long)d->capacity + kTile - 1) / kTile;
+        c->cap_own = (int)((blocks + d->world - 1) / d->world) * kTile;
+    }
     c->ev_cap = d->event_capacity > 0 ? d->event_capacity : (1 << 20);
-    c->slot_bytes = sizeof(SlotHeader) + (size_t)c->cap_own * c->rec_bytes;
+    c->slot_bytes = sizeof(SlotHeader) + (size_t)c->cap_own * (c->rec_bytes + 2 * c->real_bytes);   // records | velocities
     c->slot_bytes = (c->slot_bytes + 255) & ~(size_t)255;
 
 #define CTX_TRY(expr)                                                                                     \
@@ -503,9 +526,8 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     if (n > c->cap) return nbody_fail(NBODY_ERR_CAPACITY, "nbody_upload: %d bodies > capacity %d", n, c->cap);
     HIP_TRY(hipSetDevice(c->desc.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const int G = c->desc.world, g = c->desc.rank;
-    const int lo = (int)((long long)n * g / G), hi = (int)((long long)n * (g + 1) / G);
-    const int cnt = hi - lo;
+    int lo = 0, cnt = 0;
+    own_range_of(n, c->desc.rank, c->desc.world, &lo, &cnt);
     if (cnt > c->cap_own) return nbody_fail(NBODY_ERR_CAPACITY, "own range %d > own capacity %d", cnt, c->cap_own);
     // pack [P|V|M|R] (src/nbody.cu:66-77) into {x,y,m,r} records; Meta::summary as unpack_slots computes it per step
     int summary = 0;
@@ -542,7 +564,7 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     HIP_TRY(hipMemcpyAsync(c->meta, c->h_meta, sizeof(Meta), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->n_upper = n; c->own_upper = cnt;
+    c->n_upper = n; c->own_upper = own_upper_of(c, n);
     memset(c->h_counters, 0, sizeof(Counters));
     memset(c->h_counters_async, 0, sizeof(Counters));
     c->device_failed = false;
@@ -871,6 +893,20 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const fl
     hipLaunchKernelGGL(ref_layout_move_f32, dim3(numBlocks), dim3(kTile), 0, (hipStream_t)stream, d_bodyData,
                        d_updM, d_updR, numBodies, timestep);
     HIP_TRY(hipGetLastError());
+    return NBODY_OK;
+}
+
+int nbody_debug_force_only(nbody_ctx* c, int reps) {
+    if (!c || reps < 0) return nbody_fail(NBODY_ERR_INVALID, "nbody_debug_force_only: bad argument");
+    if (!c->uploaded) return nbody_fail(NBODY_ERR_STATE, "nbody_debug_force_only before nbody_upload");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    const int nblocks = c->own_upper / kTile > 0 ? c->own_upper / kTile : 1;
+    for (int r = 0; r < reps; ++r) {
+        int rc = c->desc.precision == NBODY_F64
+                     ? launch_force_kernel<double>(c, make_params<double>(c->desc, c->spin_limit), nblocks)
+                     : launch_force_kernel<float>(c, make_params<float>(c->desc, c->spin_limit), nblocks);
+        if (rc != NBODY_OK) return rc;
+    }
     return NBODY_OK;
 }
 

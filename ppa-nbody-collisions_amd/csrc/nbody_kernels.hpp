@@ -1645,7 +1645,7 @@ __global__ __launch_bounds__(kCompactBlock) void compact_scatter(const Rec<T>* _
                                                                  const int* __restrict__ blk_counts, int nblk,
                                                                  SlotHeader* __restrict__ slot_hdr,
                                                                  Rec<T>* __restrict__ slot_recs,
-                                                                 Vec2<T>* __restrict__ Vown) {
+                                                                 Vec2<T>* __restrict__ slot_vels) {
     __shared__ int wsum[kCompactBlock / kWave];
     __shared__ int red[kCompactBlock / kWave];
     __shared__ int base_s;
@@ -1686,33 +1686,50 @@ __global__ __launch_bounds__(kCompactBlock) void compact_scatter(const Rec<T>* _
         for (int w = 0; w < wid; ++w) off += wsum[w];
         off += __popcll(bal & ((1ull << lane) - 1ull));
         slot_recs[off] = rec;
-        Vown[off] = vel;
+        slot_vels[off] = vel;
     }
 }
 
-// Builds the step t+1 replica from the gathered slots of all ranks (global stable order = rank order) and
-// publishes the new Meta.  grid = (ceil(cap_own / 256), world).
+// The partition of N bodies over `world` ranks: whole reference blocks (128 bodies, src/nbody.cu:36), as evenly as
+// the block count allows, in rank order.  Block-aligned own ranges keep every ring / lane group of the force kernels
+// on bodies of one rank, and they are re-drawn from the survivor count after every step, so deletions never leave a
+// rank with more than its share (the reference compacts globally, :488-510).
+__host__ __device__ inline void own_range_of(int n, int rank, int world, int* lo, int* cnt) {
+    const long long blocks = ((long long)n + kTile - 1) / kTile;
+    long long first = blocks * rank / world * kTile, last = blocks * (rank + 1) / world * kTile;
+    if (first > n) first = n;
+    if (last > n) last = n;
+    *lo = (int)first;
+    *cnt = (int)(last - first);
+}
+
+// Builds step t+1 from the gathered slots of all ranks (global stable order = rank order): the replica of all
+// bodies, the velocities of THIS rank's new own range, and the new Meta.  A slot = header {count} | records[cap_own] |
+// velocities[cap_own].  grid = (ceil(cap_own / 256), world).
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restrict__ gather, size_t slot_bytes,
-                                                    int world, int rank, Rec<T>* __restrict__ J,
-                                                    Meta* __restrict__ meta) {
+                                                    int cap_own, int world, int rank, Rec<T>* __restrict__ J,
+                                                    Vec2<T>* __restrict__ Vown, Meta* __restrict__ meta) {
     const int g = blockIdx.y;
-    int off = 0, total = 0, mine_off = 0, mine_cnt = 0;
+    int off = 0, total = 0;
     for (int h = 0; h < world; ++h) {
         const int c = reinterpret_cast<const SlotHeader*>(gather + (size_t)h * slot_bytes)->count;
         if (h < g) off += c;
-        if (h < rank) mine_off += c;
-        if (h == rank) mine_cnt = c;
         total += c;
     }
+    int lo, cnt;
+    own_range_of(total, rank, world, &lo, &cnt);
     const unsigned char* slot = gather + (size_t)g * slot_bytes;
     const int c = reinterpret_cast<const SlotHeader*>(slot)->count;
     const Rec<T>* recs = reinterpret_cast<const Rec<T>*>(slot + sizeof(SlotHeader));
+    const Vec2<T>* vels = reinterpret_cast<const Vec2<T>*>(slot + sizeof(SlotHeader) + (size_t)cap_own * sizeof(Rec<T>));
     const int q = blockIdx.x * 256 + threadIdx.x;
     int bits = 0;
     if (q < c) {
         const Rec<T> r = recs[q];
-        J[off + q] = r;
+        const int i = off + q;                             // index of this body in step t+1
+        J[i] = r;
+        if (i >= lo && i < lo + cnt) Vown[i - lo] = vels[q];
         const bool bounded = abs_(r.x) < FastDomain<T>::coord && abs_(r.y) < FastDomain<T>::coord;
         bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
     }
@@ -1724,8 +1741,8 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         const int step = meta->step;
         meta->n_prev = meta->n;
         meta->n = total;
-        meta->lo = mine_off;
-        meta->cnt = mine_cnt;
+        meta->lo = lo;
+        meta->cnt = cnt;
         meta->step = step + 1;
     }
 }
