@@ -9,7 +9,9 @@ whole body set.  Workload = BASELINE.json configs[3] shape: N=262144 bodies, fp3
 condition (seed 1024), radii 0 (the "positions-only exchange" headline row of SURVEY.md 8d), literal
 reference semantics.  N>1: STRONG scaling - the same 262144 bodies range-partitioned over the ranks, one
 process per GPU, the per-step all-gather over RCCL inside the library; torch.distributed (gloo) only carries
-the 128-byte communicator id, the barriers and the max-over-ranks time.
+the 128-byte communicator id, the barriers and the max-over-ranks time.  After the timed region a multi-rank run
+checks ITSELF: the state the ranks hold (collective download) against a single-rank run of the same steps, bit for
+bit (`parity`), so a scaling line always carries its own correctness bit.
 
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region starts.
 """
@@ -29,13 +31,28 @@ PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_pmc.json")
+
+
 def measured_traffic(a, world):
-    """HBM-side bytes per force-kernel launch from the committed rocprofv3 PMC passes (profiles/, collected
-    and corrected as MI355X_MICROARCH.md prescribes). Only valid for the configuration it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+    """HBM-side bytes per force-kernel launch: NOT measured in this run (PMC counters need rocprofv3) but read from
+    the committed rocprofv3 passes of this same command (profiles/, collected in separate --pmc passes and corrected
+    as MI355X_MICROARCH.md prescribes).  Only reported for the configuration it was measured on; the JSON line
+    names the file it came from."""
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     if world != 1 or a.bodies != 262144 or a.fp64 or a.stock_radii or a.variant != 0 or not os.path.exists(path):
-        return None
-    return json.load(open(path))["forces_kernel_traffic_bytes_per_launch"]
+        return None, None
+    return json.load(open(path))["forces_kernel_traffic_bytes_per_launch"], TRAFFIC_FILE
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
@@ -65,9 +82,46 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
     oP, oV, oM, oR, _, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
     t = time.perf_counter() - t0
     base = {"value": st.pairs / t, "unit": "body-pair-interactions/sec", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": "bodies [%d,%d) of step 1 at N=%d against all j (%d pairs, %.1f s, OpenMP %d threads)" %
                       (lo, lo + count, n, st.pairs, t, threads)}
+    # the same restatement on ONE thread, about two seconds of it
+    ol.port().oracle_set_threads(1)
+    one = max(8, min(count, int(2.0 * rate / threads / per_body)))
+    t0 = time.perf_counter()
+    *_, st1 = ol.port_range(blk, n, lo, lo + one, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    t1 = time.perf_counter() - t0
+    ol.port().oracle_set_threads(threads)
+    base["single_thread"] = {"value": st1.pairs / t1, "unit": "body-pair-interactions/sec",
+                             "sample": "bodies [%d,%d) of the same step (%d pairs, %.1f s)" % (lo, lo + one, st1.pairs, t1)}
     return base, parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR)
+
+
+def parity_of_ranks(nb, st, bodies, cfg, precision, device, total_steps, rank):
+    """world > 1: the state the ranks hold after the run (collective download over RCCL: every rank calls it) against
+    a fresh SINGLE-rank stepper run for the same number of steps on rank 0's GPU.  Sharding changes who computes a
+    body, never what is computed, so the bar is bitwise equality; the single-rank path is the one the 1-GPU line checks
+    against the CPU oracle."""
+    import numpy as np
+    got = st.download()
+    if rank != 0:
+        return None
+    one = nb.Stepper(cfg, precision=precision, device=device)
+    one.upload(bodies)
+    one.step(total_steps)
+    want = one.download()
+    one.close()
+    u = np.uint64 if precision == nb.F64 else np.uint32
+    same_n = got.numBodies == want.numBodies
+    equal = bool(same_n and np.array_equal(got.block.view(u), want.block.view(u)))
+    out = {"against": "single-rank run of the same %d steps on rank 0's GPU (itself checked against the CPU oracle by "
+                      "the 1-GPU line and the test-suite)" % total_steps,
+           "bodies_after": int(got.numBodies), "bodies_after_single_rank": int(want.numBodies),
+           "bitwise_equal": equal}
+    if same_n:
+        out["max_abs_dpos"] = float(np.abs(got.Positions.astype(np.float64) - want.Positions).max())
+        out["max_abs_dvel"] = float(np.abs(got.Velocities.astype(np.float64) - want.Velocities).max())
+    return out
 
 
 def parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR):
@@ -117,6 +171,7 @@ def main():
     ap.add_argument("--stock-radii", action="store_true", help="radii 50-200 (collisions on) instead of 0")
     ap.add_argument("--fp64", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="world > 1: skip the comparison with a single-rank run")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--force-comm", action="store_true",
@@ -190,6 +245,7 @@ def main():
     s1 = st.stats()
     st.set_kernel_timing(False)
 
+    kernel_name = st.force_kernel_name()
     pairs = s1.pairs - s0.pairs
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -205,10 +261,12 @@ def main():
         k_ms = s1.force_kernel_ms / launches                  # HIP events on the launch stream
         k_pairs = (s1.pairs - s0.pairs) / launches            # pairs one launch of THIS rank evaluates
         real = 8 if a.fp64 else 4
-        alg_bytes = 12.0 * real * (s1.n_own if world > 1 else s1.n_bodies) + 4.0 * real * s1.n_bodies
-        # compulsory bytes of one launch: read the {x,y,m,r} replica once (4 reals/body) + read V and write
-        # the staged record and V of the own range (2 + 4 + 2 reals/body); world=1: 48*N fp32 = SURVEY.md 8d
+        # ALGORITHMIC (compulsory) bytes of one force-kernel launch, SURVEY.md 8d / DESIGN.md 4.1: read the {x,y,m,r}
+        # replica once (4 reals per body of the whole set) + read V (2) and write the staged record (4) and V (2) of
+        # the own range.  One rank: (4 + 8) reals * N = 48*N bytes in fp32, 96*N in fp64.
+        alg_bytes = 4.0 * real * s1.n_bodies + 8.0 * real * (s1.n_own if world > 1 else s1.n_bodies)
         peak_valu = PEAK_FP64_VALU_TFLOPS if a.fp64 else PEAK_FP32_VALU_TFLOPS
+        traffic, traffic_source = measured_traffic(a, world)
         out = {
             "metric": "body-pair-interactions/sec at N=%d" % a.bodies,
             "value": value, "unit": "body-pair-interactions/sec", "n_gpus": a.gpus, "steps": a.steps,
@@ -223,18 +281,28 @@ def main():
                        "bodies_after": s1.n_bodies,
                        "parallelism": "range-partition x%d, RCCL slot all-gather per step" % world
                        if world > 1 else "single GPU"},
+            # north_star asks for the HBM fraction; the roof that BINDS this kernel is the fp32/fp64 vector ALU
+            # (arithmetic intensity ~1e5 flop/B): its fraction is roofline.valu, computed from the same live kernel time
             "roofline": {"bound": "hbm", "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
                          "unit": "GB/s", "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                         "traffic": measured_traffic(a, world), "kernel": "forces", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes},
-            "roofline_valu": {"bound": "valu_fp32" if not a.fp64 else "valu_fp64",
-                              "achieved": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12, "peak": peak_valu,
-                              "unit": "TFLOP/s",
-                              "frac": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12 / peak_valu,
-                              "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": k_pairs},
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name, "kernel_ms": k_ms, "kernel_launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes, "binding": "valu",
+                         "valu": {"bound": "valu_fp32" if not a.fp64 else "valu_fp64",
+                                  "achieved": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12, "peak": peak_valu,
+                                  "unit": "TFLOP/s",
+                                  "frac": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12 / peak_valu,
+                                  "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": k_pairs}},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
+    if (world > 1 or a.force_comm) and not a.no_parity:
+        # every rank takes part (the download is a collective); rank 0 compares and reports
+        par = parity_of_ranks(nb, st, bodies, cfg, precision, local_rank, a.warmup + a.steps, rank)
+        if rank == 0:
+            out["parity" if world > 1 else "parity_rccl_path"] = par
+            out["config"]["rccl_ranks"] = world
+    if rank == 0:
         print(json.dumps(out), flush=True)
     st.close()
     if dist is not None:

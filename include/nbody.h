@@ -150,10 +150,11 @@ typedef struct nbody_ctx_desc {
     int fieldWidth;         /* kernel args :482                                                         */
     int fieldHeight;
     const void* comm_id;    /* world>1 with RCCL: 128-byte id from nbody_comm_unique_id on rank 0       */
-    int kernel_variant;     /* 0 = automatic (by own-range size); tuning / A-B testing only: 1 general kernel, */
-                            /* 11/12/14/18 one-lane..eight-lanes-per-body kernel, 31/32 its 256-thread form,   */
-                            /* 40 producer/consumer kernel, 50 ring-of-waves kernel (51-59: its tuning forms). fp64: 1 selects the */
-                            /* general kernel, anything else the fp64 production kernel                         */
+    int kernel_variant;     /* 0 = automatic (by own-range size); tuning / A-B testing only: 1 general kernel,  */
+                            /* 11/12/14/18 one-lane..eight-lanes-per-body kernel, 31/32 its 256-thread form,    */
+                            /* 50/52/54 ring-of-waves kernel with 2x8 / 4x4 / 1x8 (rings x waves) workgroups    */
+                            /* (53, 58: its tuning forms).  fp64: 1 selects the general kernel, anything else   */
+                            /* the fp64 production kernel                                                       */
 } nbody_ctx_desc;
 
 void nbody_ctx_desc_from_config(nbody_ctx_desc* d, const nbody_config* cfg, int precision);
@@ -201,6 +202,8 @@ typedef struct nbody_stats {
 int nbody_get_stats(nbody_ctx* ctx, nbody_stats* out);  /* synchronises */
 /* Bracket every force-kernel launch with HIP events on the context's stream (bench / profiling). */
 int nbody_set_kernel_timing(nbody_ctx* ctx, int enable);
+/* Which force kernel the next step of this context launches (static string; reporting only). */
+const char* nbody_force_kernel_name(nbody_ctx* ctx);
 
 /* Image output.  nbody_render_image = cudaMemsetAsync(254) + generateImage + D2H
  * (src/nbody.cu:531-537, kernel :294-348): bodies drawn as filled discs of value 0 into img[width*height]; the

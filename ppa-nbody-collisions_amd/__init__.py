@@ -107,6 +107,7 @@ SYMBOLS = {
     "nbody_clear_events": (_i, [_vp]),
     "nbody_get_stats": (_i, [_vp, ctypes.POINTER(Stats)]),
     "nbody_set_kernel_timing": (_i, [_vp, _i]),
+    "nbody_force_kernel_name": (ctypes.c_char_p, [_vp]),
     "nbody_render_image": (_i, [_vp, _vp, _i, _i]),
     "nbody_write_pgm": (_i, [ctypes.c_char_p, _vp, _i, _i]),
     "nbody_ctx_info": (_i, [_vp, ctypes.POINTER(_CtxDesc), ctypes.POINTER(ctypes.c_int64)]),
@@ -376,6 +377,9 @@ class Stepper:
 
     def clear_events(self):
         _check(lib.nbody_clear_events(self._ctx))
+
+    def force_kernel_name(self):
+        return lib.nbody_force_kernel_name(self._ctx).decode()
 
     def set_kernel_timing(self, enable=True):
         _check(lib.nbody_set_kernel_timing(self._ctx, int(enable)))

@@ -206,7 +206,7 @@ int read_meta(nbody_ctx* c) {
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
 //                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body, 128-thread workgroups |
 //                 31,32 v3 K = 1 with 256-thread workgroups, registers sized for 4 / 2 waves per SIMD |
-//                 40 pc8 (producer/consumer) | 50 ring of waves
+//                 50,52,54 ring of waves with 2x8, 4x4, 1x8 (rings x waves) per workgroup; 53,58 its tuning forms
 template <typename T>
 void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
 
@@ -240,24 +240,12 @@ void launch_v3w(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log)
     else hipLaunchKernelGGL((forces_v3w_f32<K, false, kOcc>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(float));
 }
 
-inline void launch_pc8(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
-    const int grid = nblocks * 2;                          // two 64-body workgroups per reference block
-    if (log) hipLaunchKernelGGL((forces_pc8_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_pc8_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-}
-
-template <int kW, int kT, int kSleep, bool kProbe, int kRings, int kExp = 0>
+template <int kW, int kT, int kSleep, bool kProbe, int kRings>
 void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = (nblocks * 2 + kRings - 1) / kRings;  // a workgroup serves kRings rings of 64 bodies, two per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings, kExp>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings, kExp>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
 }
-inline void launch_ring_r1(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
-    const int grid = nblocks * 2;
-    if (log) hipLaunchKernelGGL((forces_ring_r1_f32<true>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_r1_f32<false>), dim3(grid), dim3(8 * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-}
-
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     switch (c->desc.kernel_variant) {
@@ -271,17 +259,11 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 18: launch_v3<8>(c, p, nblocks, log); return;
         case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
         case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
-        case 40: launch_pc8(c, p, nblocks, log); return;
-        case 50: launch_ring<8, 32, 1, false, 2>(c, p, nblocks, log); return;   // 2 rings of 8 waves per workgroup
-        case 51: launch_ring<8, 32, 0, false, 2>(c, p, nblocks, log); return;   // tuning: no s_sleep in the poll
-        case 52: launch_ring<4, 32, 1, false, 4>(c, p, nblocks, log); return;   // 4 rings of 4 waves per workgroup
-        case 53: launch_ring<8, 16, 1, false, 2>(c, p, nblocks, log); return;   // tuning: turns of 16 positions
-        case 54: launch_ring<8, 32, 1, false, 1>(c, p, nblocks, log); return;   // tuning: one ring per workgroup
-        case 55: launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log); return;   // tuning: longer s_sleep
-        case 56: launch_ring<4, 32, 1, false, 2>(c, p, nblocks, log); return;   // tuning: 2 rings of 4 waves
-        case 63: launch_ring<4, 32, 2, false, 4, 0>(c, p, nblocks, log); return;   // tuning: s_sleep 2
-        case 58: launch_ring<8, 32, 1, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
-        case 59: launch_ring_r1(c, p, nblocks, log); return;                    // round-1 form, A/B only
+        case 50: launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log); return;   // 2 rings of 8 waves per workgroup
+        case 52: launch_ring<4, 32, 2, false, 4>(c, p, nblocks, log); return;   // 4 rings of 4 waves per workgroup
+        case 54: launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log); return;   // one ring of 8 waves per workgroup
+        case 53: launch_ring<8, 16, 2, false, 2>(c, p, nblocks, log); return;   // tuning: turns of 16 positions
+        case 58: launch_ring<8, 32, 2, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many ordered chains there are to fill the chip with
@@ -292,9 +274,9 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //                   (4.35 ms at 32768 own bodies of 262144; 4 x 4: 5.4)
     //   below         : ring kernel, one ring of 8 waves per workgroup: twice the workgroups to spread over the CUs
     //                   (0.21 ms at N = 16384; 2 x 8: 0.29; the producer/consumer kernel of round 1: 0.31)
-    if (c->own_upper >= 49152) launch_ring<4, 32, 1, false, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 24576) launch_ring<8, 32, 1, false, 2>(c, p, nblocks, log);
-    else launch_ring<8, 32, 1, false, 1>(c, p, nblocks, log);
+    if (c->own_upper >= 49152) launch_ring<4, 32, 2, false, 4>(c, p, nblocks, log);
+    else if (c->own_upper >= 24576) launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log);
+    else launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log);
 }
 
 template <typename T>
@@ -894,6 +876,24 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const fl
                        d_updM, d_updR, numBodies, timestep);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
+}
+
+const char* nbody_force_kernel_name(nbody_ctx* c) {
+    if (!c) return "";
+    if (c->desc.precision == NBODY_F64) return c->desc.kernel_variant == 1 ? "forces_v1<double>" : "forces_v3w_f64";
+    switch (c->desc.kernel_variant) {
+        case 1: return "forces_v1<float>";
+        case 11: case 12: case 14: case 18: return "forces_v3_f32";
+        case 31: case 32: return "forces_v3w_f32";
+        case 50: case 58: return "forces_ring_f32 (2 rings x 8 waves per workgroup)";
+        case 52: return "forces_ring_f32 (4 rings x 4 waves per workgroup)";
+        case 53: return "forces_ring_f32 (2 rings x 8 waves, 16-position turns)";
+        case 54: return "forces_ring_f32 (1 ring x 8 waves per workgroup)";
+        default: break;
+    }
+    if (c->own_upper >= 49152) return "forces_ring_f32 (4 rings x 4 waves per workgroup)";
+    if (c->own_upper >= 24576) return "forces_ring_f32 (2 rings x 8 waves per workgroup)";
+    return "forces_ring_f32 (1 ring x 8 waves per workgroup)";
 }
 
 int nbody_debug_force_only(nbody_ctx* c, int reps) {

@@ -582,314 +582,6 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 #undef NB_V3_COUNT
 
 // ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "pc8" (fp32, producer / consumer): for ranks that own far fewer
-// bodies than the chip has lanes (strong scaling).
-//
-// The per-body force sum is a strictly ordered chain of N fp32 adds; only the TERMS are independent, and a wave
-// cannot issue more than one VALU per ~5 cycles, so with N/G bodies per GPU there are too few chains to keep
-// the SIMDs busy.  A workgroup of 8 waves serves 64 bodies: wave 0 is the chain wave (one lane per body, so
-// every chain add instruction does 64 useful adds), waves 1..7 are producers.  A sub-tile is half a tile (64
-// walk positions): producer p evaluates positions [9p, 9p+9) with the fast chain and stores the terms in LDS
-// (two consecutive positions of a lane share a 16-byte slot), the chain wave evaluates position 63 itself, so
-// all 8 waves carry about the same instruction count (9 pairs ~ 63 chain adds + 1 pair).  One barrier per
-// sub-tile; term hand-over is double buffered and the chain wave runs one sub-tile behind the producers, also
-// across tile boundaries.  Producers never touch masses, radii, deletions or events: positions they flag
-// (possible collision / distance below the proved domain) are reported per sub-tile as a 64-bit lane mask and
-// the chain lane redoes that sub-tile with the general code.  First / last tile of a walk (self skip,
-// truncation) and tiles with unbounded coordinates are done by the chain wave alone.
-//
-// Geometry from measurement (profiles/): the dispatcher starts every workgroup on the same SIMD, so two 9-wave
-// workgroups need 6 wave slots there and 5-wave workgroups leave 2.1 waves per SIMD resident; 8 waves land
-// 2-2-2-2 and two workgroups per CU give 4 waves per SIMD.  Short sub-tiles stall on the barrier; reads of
-// tile records and terms are issued in batches ahead of their use (nothing else hides LDS latency at this
-// occupancy).  Results are bit-identical to every other variant.
-// ---------------------------------------------------------------------------------------------------------
-template <bool kLog>
-__global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void forces_pc8_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
-                    Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
-                    StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
-    typedef float T;
-    constexpr int kP = 7;                                  // producer waves
-    constexpr int kS = 64;                                 // positions per sub-tile
-    constexpr int kPer = 9;                                // positions per producer per sub-tile (7 * 9 = 63)
-    constexpr int kSubs = kTile / kS;
-    __shared__ Rec<T> tile[2][2 * kTile];                  // each tile stored twice: no wrap in the walk
-    // two consecutive positions of a lane share a 16-byte slot: the chain wave reads 32 slots per sub-tile
-    struct alignas(16) Term2 { Vec2<T> p[2]; };
-    __shared__ Term2 terms[2][kS / 2][kWave];
-    __shared__ unsigned long long flagmask[2][8];
-    __shared__ int tile_bad[2][2];
-    __shared__ int wg_bad;
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-    const int tid = threadIdx.x;
-    const int wave = tid / kWave;
-    const int l = tid % kWave;
-    const bool consumer = wave == 0;
-    const int pw = wave - 1;                               // producer index (valid when !consumer)
-    const int wg = blockIdx.x;
-    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
-    const int t = (wg % 2) * kWave + l;                    // threadIdx.x of this lane's body in the reference
-    const long long blk0 = (long long)b * kTile;
-    if (blk0 + (wg % 2) * kWave >= (long long)lo + cnt) return;
-    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool lit = p.literal != 0;                       // else NBODY_CLEAN: see forces_v3_f32
-    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
-    const int wbase = lit ? t : 0;                         // tile entry of walk position 0 for this lane
-
-    const long long i64 = blk0 + t;
-    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
-    BodyAcc<T> a;
-    Vec2<T> v{0, 0};
-    if (mine) {
-        const Rec<T> me = J[i];
-        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
-        if (consumer) v = Vown[i - lo];
-    } else {
-        a.xi = a.yi = a.mi = a.ri = 0;
-    }
-    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
-    unsigned long long pairs = 0;
-
-    if (consumer) __builtin_amdgcn_s_setprio(3);           // the chain wave carries the serial part
-    if (tid == 0) wg_bad = 0;
-    __syncthreads();
-    {
-        const bool lane_ok = !active || ((__builtin_fabsf(a.xi) < kCoordBound) && (__builtin_fabsf(a.yi) < kCoordBound));
-        if (consumer && __ballot(!lane_ok) != 0ull && l == 0) atomicOr(&wg_bad, 1);
-    }
-    long long start = lit ? blk0 % N : 0;                  // first body of the current tile
-    // this thread's entry of the tile starting at body st, or -1 if it has none
-    auto entry_index = [&](long long st) -> int {
-        if (tid >= kTile) return -1;
-        long long src = st + tid;
-        if (!lit) return src < N ? (int)src : -1;
-        if (N < kTile && tid >= N) return -1;              // lanes >= N load nothing (:143)
-        if (src >= N) src -= N;
-        if (src >= N) src %= N;                            // only when N < 128
-        return (int)src;
-    };
-    auto tile_len = [&](int kk, long long st) -> int {
-        if (lit) return (kk == nb - 1) ? N % (kTile + 1) : kTile;             // :194 (quirk Q1)
-        return (N - st) < kTile ? (int)(N - st) : kTile;
-    };
-    auto coord_bad = [](const Rec<T>& r) -> bool {
-        return !((__builtin_fabsf(r.x) < kCoordBound) && (__builtin_fabsf(r.y) < kCoordBound));
-    };
-    if (tid < kTile) {
-        Rec<T> r{0, 0, 0, 0};
-        const int e = entry_index(start);
-        if (e >= 0) { r = J[e]; tile[0][tid] = r; tile[0][tid + kTile] = r; }
-        const bool bad = __ballot(e >= 0 && coord_bad(r)) != 0ull;
-        if (l == 0) tile_bad[0][wave] = bad;
-    }
-    __syncthreads();
-    const bool all_ok = wg_bad == 0;
-
-    // the fast evaluation of one walk position
-    auto term = [&](const Rec<T>& bj, unsigned long long& flag, float& tx, float& ty) {
-        const float dx = bj.x - a.xi;
-        const float dy = bj.y - a.yi;
-        const float d2 = (dx * dx) + (dy * dy);
-        const float rs = a.ri + bj.r;
-        const float q = __builtin_fmaf(rs, rs, kFastLo);                       // flag only
-        flag |= __builtin_amdgcn_fcmpf(d2, q, 5 /* llvm::CmpInst::FCMP_OLE */);
-        const FastChain ch = fast_chain(d2);
-        tx = ch.inv * (bj.m * dx);
-        ty = ch.inv * (bj.m * dy);
-    };
-    // two walk positions at once on 2-vectors, as in the one-lane kernel (nbody_forces_v3.inc)
-    auto term2 = [&](const Rec<T>& ba, const Rec<T>& bb, unsigned long long& flag, Vec2<T>& ta, Vec2<T>& tb) {
-        typedef Pair<float>::type V2;
-        V2 own, pa, pb;
-        own.x = a.xi; own.y = a.yi;
-        pa.x = ba.x; pa.y = ba.y;
-        pb.x = bb.x; pb.y = bb.y;
-        const V2 da = pa - own, db = pb - own;
-        const V2 sa = da * da, sb = db * db;
-        V2 d2, q, rs;
-        d2.x = add_unmerged(sa.x, sa.y);
-        d2.y = add_unmerged(sb.x, sb.y);
-        rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
-        q.x = kFastLo; q.y = kFastLo;
-        q = __builtin_elementwise_fma(rs, rs, q);                              // flag only
-        flag |= le_mask(d2.x, q.x);
-        flag |= le_mask(d2.y, q.y);
-        const V2 inv = fast_inv_cube2(d2);
-        const V2 va = (da * ba.m) * inv.x, vb = (db * bb.m) * inv.y;
-        ta = Vec2<T>{va.x, va.y};
-        tb = Vec2<T>{vb.x, vb.y};
-    };
-    // chain-lane general code on walk positions [o0, o1) of tile kk (buffer kk & 1, first body st)
-    auto general = [&](int kk, long long st, int o0, int o1) {
-        const int L = tile_len(kk, st);
-        const int hi = o1 < L ? o1 : L;
-        for (int off = o0; off < hi; ++off) {
-            int s;
-            long long j;
-            if (lit) {
-                if (kk == 0 && off == 0) continue;                             // :200-204
-                s = (L == kTile) ? (t + off) : ((t + off) % L);                // :207 (doubled tile: no wrap)
-                j = st + ((L == kTile) ? ((t + off) & (kTile - 1)) : s);
-                if (j >= N) j %= N;
-            } else {
-                s = off;
-                j = st + off;
-                if (j == i64) continue;
-            }
-            interact<T, kLog>(a, tile[kk & 1][s], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-        }
-    };
-    // chain wave: the 63 producer terms of a finished sub-tile in walk order, then its own position 63
-    auto drain = [&](int buf, int kk, long long st, int sub) {
-        unsigned long long mask = 0;
-#pragma unroll
-        for (int q = 0; q < kP; ++q) mask |= flagmask[buf][q];
-        const float fx0 = a.fx, fy0 = a.fy;
-        float fx = fx0, fy = fy0;
-        const Rec<T> own = tile[kk & 1][wbase + sub * kS + (kS - 1)];
-#pragma unroll 1
-        for (int o0 = 0; o0 < 24; o0 += 8) {               // positions 0..47
-            Term2 tm[8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) tm[o] = terms[buf][o0 + o][l];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                fx = fx + tm[o].p[0].x; fy = fy + tm[o].p[0].y;
-                fx = fx + tm[o].p[1].x; fy = fy + tm[o].p[1].y;
-            }
-        }
-        {                                                  // positions 48..62 from LDS, 63 evaluated here
-            Term2 tm[8];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) tm[o] = terms[buf][24 + o][l];
-            unsigned long long own_flag = 0;
-            float tx, ty;
-            term(own, own_flag, tx, ty);
-            if (own_flag != 0ull) mask = ~0ull;
-#pragma unroll
-            for (int o = 0; o < 7; ++o) {
-                fx = fx + tm[o].p[0].x; fy = fy + tm[o].p[0].y;
-                fx = fx + tm[o].p[1].x; fy = fy + tm[o].p[1].y;
-            }
-            fx = fx + tm[7].p[0].x; fy = fy + tm[7].p[0].y;
-            fx = fx + tx;
-            fy = fy + ty;
-        }
-        a.fx = fx; a.fy = fy;
-        if (mask != 0ull) {
-            if (((mask >> l) & 1ull) && active) {
-                a.fx = fx0; a.fy = fy0;
-                general(kk, st, sub * kS, sub * kS + kS);
-            }
-        }
-    };
-
-    bool pending = false;
-    int pend_buf = 0, pend_k = 0, pend_sub = 0;
-    long long pend_start = 0;
-    int gsub = 0;
-    for (int k = 0; k < ntiles; ++k) {                     // :182, literal: tile k of these bodies = cyclic tile b + k
-        const int cur = k & 1;
-        const bool have_next = k + 1 < ntiles;
-        long long next_start = start + kTile;
-        if (lit) while (next_start >= N) next_start -= N;
-        Rec<T> nxt{0, 0, 0, 0};
-        const int e_next = have_next ? entry_index(next_start) : -1;
-        if (e_next >= 0) nxt = J[e_next];
-        // the other tile buffer is free from here on: its last readers (the chain wave's work on tile k-1's
-        // final sub-tile) ran before the first barrier of tile k
-        auto stage_next = [&]() {
-            if (have_next && tid < kTile) {
-                if (e_next >= 0) { tile[cur ^ 1][tid] = nxt; tile[cur ^ 1][tid + kTile] = nxt; }
-                const bool bad = __ballot(e_next >= 0 && coord_bad(nxt)) != 0ull;
-                if (l == 0) tile_bad[cur ^ 1][wave] = bad;
-            }
-        };
-        const bool bad_tile = (tile_bad[cur][0] | tile_bad[cur][1]) != 0;
-        const int Lk = tile_len(k, start);
-        // tiles whose every position is an ordinary pair for every lane of the workgroup (workgroup-uniform)
-        const bool interior = lit ? (k >= 1 && k <= nb - 2) : (Lk == kTile && k != b);
-        const bool fast_tile = interior && all_ok && !bad_tile;
-        if (fast_tile) {
-#pragma unroll 1
-            for (int sub = 0; sub < kSubs; ++sub) {
-                const int buf = gsub & 1;
-                if (!consumer) {
-                    unsigned long long flag = 0;
-                    const Rec<T>* walk = &tile[cur][wbase + sub * kS + pw * kPer];
-                    Rec<T> rec[kPer];
-#pragma unroll
-                    for (int r = 0; r < kPer; ++r) rec[r] = walk[r];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r + 1 < kPer; r += 2) {
-                        Vec2<T> ta, tb;
-                        term2(rec[r], rec[r + 1], flag, ta, tb);
-                        terms[buf][(pw * kPer + r) / 2][l].p[(pw * kPer + r) & 1] = ta;
-                        terms[buf][(pw * kPer + r + 1) / 2][l].p[(pw * kPer + r + 1) & 1] = tb;
-                    }
-                    static_assert(kPer % 2 == 1, "the last position of a producer is evaluated alone");
-                    {
-                        float tx, ty;
-                        term(rec[kPer - 1], flag, tx, ty);
-                        terms[buf][(pw * kPer + kPer - 1) / 2][l].p[(pw * kPer + kPer - 1) & 1] = Vec2<T>{tx, ty};
-                    }
-                    if (l == 0) flagmask[buf][pw] = flag;
-                } else if (pending) {
-                    drain(pend_buf, pend_k, pend_start, pend_sub);
-                }
-                // the last sub-tile of tile k-1 is drained during sub-tile 0 of tile k, so the buffer of tile k-1
-                // may only be overwritten from sub-tile 1 on
-                if (sub == kSubs - 1) stage_next();
-                __syncthreads();
-                pending = true; pend_buf = buf; pend_k = k; pend_start = start; pend_sub = sub;
-                ++gsub;
-            }
-        } else {
-            if (consumer) {
-                if (pending) drain(pend_buf, pend_k, pend_start, pend_sub);
-                if (active) general(k, start, 0, kTile);
-            }
-            pending = false;
-        }
-        if (consumer && active) {
-            if (lit) pairs += (k == 0) ? (Lk > 0 ? Lk - 1 : 0) : Lk;
-            else pairs += Lk - ((i64 >= start && i64 < start + Lk) ? 1 : 0);
-        }
-        if (!fast_tile) {
-            // the chain wave may still be reading tile k-1 (its drain of that tile's last sub-tile above): the
-            // buffer stage_next() overwrites.  Everyone waits for it before the staging write.
-            __syncthreads();
-            stage_next();
-            __syncthreads();
-        }
-        start = next_start;
-    }
-    if (consumer && pending) drain(pend_buf, pend_k, pend_start, pend_sub);
-
-    if (consumer) {
-        if (mine) {
-            const int q = i - lo;
-            if (active) {
-                Rec<T> out; Vec2<T> vout;
-                finish_body<T>(a, v, p, out, vout);
-                S_J[q] = out;
-                S_V[q] = vout;
-            } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
-                S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
-                S_V[q] = v;
-            }
-        }
-        for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
-        if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Force + collision + drift kernel, variant "ring" (fp32): for own ranges with fewer chains than the chip has lanes.
 //
 // A workgroup of kW waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
@@ -935,7 +627,7 @@ __device__ __forceinline__ void load_to_lds_b128(const void* base, unsigned byte
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
 
-template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings, int kExp = 0>
+template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings>
 __global__ __launch_bounds__(kRings * kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
                      Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
@@ -1163,10 +855,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 for (int r0 = 0; r0 < kT; r0 += kG) {
                     Rec<T> rec[kG];
 #pragma unroll
-                    for (int u = 0; u < kG; ++u) {
-                        rec[u] = walk[r0 + u];
-                        if (kExp & 2) asm volatile("" : "+v"(rec[u].x), "+v"(rec[u].y), "+v"(rec[u].m), "+v"(rec[u].r));
-                    }
+                    for (int u = 0; u < kG; ++u) rec[u] = walk[r0 + u];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < kG; u += 2) {
@@ -1331,287 +1020,6 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                                  (int)((__builtin_amdgcn_s_getreg((31 << 11) | 20) << 20) | (unsigned)wg)};
         }
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "ring", ROUND-1 form kept for A/B only (fp32): for own ranges with fewer chains than the chip has lanes.
-//
-// A workgroup of 8 waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
-// turns of 32 positions and the turns go round the waves: wave w takes turns w, w + 8, w + 16, ...  For its turn a
-// wave (1) loads the 95 tile entries its lanes need straight from the replica into a private LDS window (direct-to-LDS
-// loads, prefetched one turn of its own ahead), (2) evaluates the 32 terms of every lane into registers - this is 14 of the 15
-// instructions per pair and depends on nothing -, (3) waits until the running state {fx, fy, mnew, rnew, deleted}
-// after the previous turn has been published in LDS by the wave before it, (4) adds its 32 terms to it in walk order
-// (or, for a flagged lane / a special tile, runs the general code on the 32 positions), and (5) publishes the
-// state for the next wave.  So the ordered chain of every body passes through all eight waves in turn, each holding it
-// only for 32 adds, while the other seven evaluate terms: no wave is a dedicated (half idle) chain wave, no term
-// goes through LDS, there is no workgroup barrier in the loop, and the instruction count per pair is that of the
-// one-lane kernel.  The hand-off is a sequence number in LDS that the next wave polls; LDS operations of a wave
-// execute in order, so the state is visible before the number.  Every wave leaves after its last turn.
-// First / last tile of a walk (self skip, truncation), the clean semantics' own tile and windows with unbounded
-// coordinates are done by the general code with records fetched from the replica.
-// ---------------------------------------------------------------------------------------------------------
-template <bool kLog>
-__global__ __launch_bounds__(8 * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void forces_ring_r1_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
-                     Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
-                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
-    typedef float T;
-    typedef Pair<float>::type V2;
-    constexpr int kW = 8;                                  // waves in the ring
-    constexpr int kT = 32;                                 // walk positions per turn
-    constexpr int kTurnsPerTile = kTile / kT;
-    constexpr int kWin = kWave + kT;                       // window entries a turn can touch (95 used)
-    __shared__ Rec<T> win[kW][2][kWin];                    // per wave, double buffered
-    struct alignas(8) HandF { float fx, fy; };             // state after a turn, two LDS accesses per lane
-    struct alignas(16) HandM { float mnew, rnew; int deleted, pad; };
-    __shared__ HandF hand_f[2][kWave];
-    __shared__ HandM hand_m[2][kWave];
-    __shared__ int seq;                                    // number of turns whose state has been published
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-    const int tid = threadIdx.x;
-    const int w = tid / kWave;
-    const int l = tid % kWave;
-    const int wg = blockIdx.x;
-    const int b = lo / kTile + wg / 2;                     // reference block; two workgroups per block
-    const int t0 = (wg % 2) * kWave;
-    const int t = t0 + l;                                  // threadIdx.x of this lane's body in the reference
-    const long long blk0 = (long long)b * kTile;
-    if (blk0 + t0 >= (long long)lo + cnt) return;
-    const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool lit = p.literal != 0;
-    const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
-    const int nturns = ntiles * kTurnsPerTile;
-
-    const long long i64 = blk0 + t;
-    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
-    BodyAcc<T> a;
-    if (mine) {
-        const Rec<T> me = J[i];
-        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
-    } else {
-        a.xi = a.yi = a.mi = a.ri = 0;
-    }
-    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
-    const bool lane_ok = !active || ((abs_(a.xi) < kCoordBound) && (abs_(a.yi) < kCoordBound));
-    const bool wave_ok = __ballot(!lane_ok) == 0ull;
-    const bool wave_r0 = __ballot(active && not_plus_zero(a.ri)) == 0ull;
-    unsigned long long pairs = 0;
-    if (tid == 0) seq = 0;
-    __syncthreads();                                       // the only workgroup barrier: seq is initialised
-
-    // First body of the tile of this wave's current turn (literal: cyclic tile b + kk), kept incrementally: a wave
-    // moves on by kW turns = two tiles at a time, and a division here would cost as much as the turn's arithmetic.
-    auto tile_start_slow = [&](int kk) -> long long {
-        if (!lit) return (long long)kk * kTile;
-        return (blk0 % N + (long long)kk * kTile) % N;
-    };
-    auto two_tiles_on = [&](long long st) -> long long {
-        st += 2 * kTile;
-        if (lit) {                                         // a next tile exists only when N >= 256: two wraps suffice
-            if (st >= N) st -= N;
-            if (st >= N) st -= N;
-        }
-        return st;
-    };
-    auto tile_len = [&](int kk, long long st) -> int {
-        if (lit) return (kk == nb - 1) ? N % (kTile + 1) : kTile;             // :194 (quirk Q1)
-        return (N - st) < kTile ? (int)(N - st) : kTile;
-    };
-    // is every position of tile kk an ordinary pair for every lane of the workgroup?
-    auto interior = [&](int kk, long long st) -> bool {
-        return lit ? (kk >= 1 && kk <= nb - 2) : (tile_len(kk, st) == kTile && kk != b);
-    };
-    // the window of a fast turn: entry j of the window is tile entry (wbase0 + off0 + j) mod 128
-    const int wbase0 = lit ? t0 : 0;                       // literal: lane l reads window[l + r]; clean: window[r]
-    const int nwin = lit ? (kWave + kT - 1) : kT;          // entries of the window that are used
-    auto window_body = [&](long long st, int off0, int j) -> int {
-        const int e = (wbase0 + off0 + j) & (kTile - 1);
-        long long src = st + e;
-        if (lit && src >= N) src -= N;                     // interior tiles only: N >= 384, one wrap
-        return (int)src;
-    };
-    // The window of turn tau, loaded from the replica STRAIGHT INTO LDS (global_load_lds_dwordx4: lane l's 16 bytes
-    // land at base + 16 l), so a prefetch holds no registers and can stay in flight for a whole turn.  Returns
-    // whether the turn can take the fast path as far as is known before the data has arrived.
-    auto issue_window = [&](int tau, long long st, int buf) -> bool {
-        if (tau >= nturns) return false;
-        const int kk = tau / kTurnsPerTile;
-        if (!(interior(kk, st) && wave_ok)) return false;
-        const int off0 = (tau % kTurnsPerTile) * kT;
-        typedef const void __attribute__((address_space(1)))* GlobalPtr;
-        typedef void __attribute__((address_space(3)))* LdsPtr;
-        if (l < nwin)
-            __builtin_amdgcn_global_load_lds((GlobalPtr)(J + window_body(st, off0, l)), (LdsPtr)&win[w][buf][0], 16, 0, 0);
-        if (l + kWave < nwin)
-            __builtin_amdgcn_global_load_lds((GlobalPtr)(J + window_body(st, off0, l + kWave)),
-                                             (LdsPtr)&win[w][buf][kWave], 16, 0, 0);
-        return true;
-    };
-    // after the loads have landed: are all coordinates of the window bounded, is some radius not +0.0f
-    struct WindowState { bool fast, rnz; };
-    auto check_window = [&](bool issued, int buf) -> WindowState {
-        if (!issued) return WindowState{false, true};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
-        if (l < nwin) r0 = win[w][buf][l];
-        if (l + kWave < nwin) r1 = win[w][buf][l + kWave];
-        const bool bad0 = !((abs_(r0.x) < kCoordBound) && (abs_(r0.y) < kCoordBound));
-        const bool bad1 = !((abs_(r1.x) < kCoordBound) && (abs_(r1.y) < kCoordBound));
-        WindowState ws;
-        ws.fast = __ballot(bad0 || bad1) == 0ull;
-        // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
-        ws.rnz = __ballot(not_plus_zero(r0.r) || not_plus_zero(r1.r)) != 0ull;
-        return ws;
-    };
-    // one walk position by the general code, record fetched from the replica
-    auto general_at = [&](int kk, long long st, int L, int off) {
-        int sidx;
-        long long j;
-        if (lit) {
-            if (kk == 0 && off == 0) return;                                   // :200-204
-            sidx = (L == kTile) ? ((t + off) & (kTile - 1)) : ((t + off) % L); // :207
-            j = st + sidx;
-            if (j >= N) j %= N;
-        } else {
-            j = st + off;
-            if (j == i64) return;
-        }
-        interact<T, kLog>(a, J[j], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-    };
-
-    long long st = tile_start_slow(w / kTurnsPerTile);
-    int buf = 0;
-    WindowState cur = check_window(issue_window(w, st, buf), buf);
-    for (int tau = w; tau < nturns; tau += kW) {
-        const int kk = tau / kTurnsPerTile;
-        const int off0 = (tau % kTurnsPerTile) * kT;
-        const int L = tile_len(kk, st);
-        const bool fast = cur.fast;
-        const long long st_next = two_tiles_on(st);
-        const bool issued_next = issue_window(tau + kW, st_next, buf ^ 1);   // in flight for the whole turn
-        // (2) the 32 terms of this turn
-        V2 term[kT];
-        unsigned long long flag = 0;
-        if (fast) {
-            const Rec<T>* walk = &win[w][buf][lit ? l : 0];
-            V2 own;
-            own.x = a.xi; own.y = a.yi;
-            auto evaluate = [&](auto r0_tag) {
-                constexpr bool kR0 = decltype(r0_tag)::value;
-                constexpr int kG = kR0 ? 8 : 4;            // reads per batch: the 32 terms already take 64 VGPRs
-#pragma unroll
-                for (int r0 = 0; r0 < kT; r0 += kG) {
-                    Rec<T> rec[kG];
-#pragma unroll
-                    for (int u = 0; u < kG; ++u) rec[u] = walk[r0 + u];
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < kG; u += 2) {
-                        const Rec<T> ba = rec[u], bb = rec[u + 1];
-                        V2 pa, pb;
-                        pa.x = ba.x; pa.y = ba.y;
-                        pb.x = bb.x; pb.y = bb.y;
-                        const V2 da = pa - own, db = pb - own;
-                        const V2 sa = da * da, sb = db * db;
-                        V2 d2, q;
-                        d2.x = add_unmerged(sa.x, sa.y);
-                        d2.y = add_unmerged(sb.x, sb.y);
-                        q.x = kFastLo; q.y = kFastLo;
-                        if (!kR0) {
-                            V2 rs;
-                            rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
-                            q = __builtin_elementwise_fma(rs, rs, q);          // flag only
-                        }
-                        flag |= le_mask(d2.x, q.x);
-                        flag |= le_mask(d2.y, q.y);
-                        const V2 inv = fast_inv_cube2(d2);
-                        term[r0 + u] = (da * ba.m) * inv.x;
-                        term[r0 + u + 1] = (db * bb.m) * inv.y;
-                    }
-                }
-            };
-            if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
-            else evaluate(std::false_type{});
-        }
-        // (3) the state after turn tau - 1
-        if (tau > 0) {
-            int spins = 0;
-            while (*(volatile int*)&seq < tau) {
-                if (++spins > (1 << 26)) {                 // never seen; keeps a broken build from hanging the GPU
-                    if (l == 0) atomicAdd(&ctr->errors, 1ull);
-                    break;
-                }
-            }
-            asm volatile("" ::: "memory");                 // the state is read after the number (in-order LDS)
-            __builtin_amdgcn_s_setprio(3);                 // holding the chain: this wave's instructions go first
-            const int hp = tau & 1;
-            const HandF hf = hand_f[hp][l];
-            const HandM hm = hand_m[hp][l];
-            a.fx = hf.fx; a.fy = hf.fy;
-            a.mnew = hm.mnew; a.rnew = hm.rnew; a.deleted = hm.deleted;
-        }
-        // (4) this turn's positions, in walk order
-        if (fast) {
-            if (active) {
-                if ((flag >> l) & 1ull) {
-#pragma unroll 1
-                    for (int r = 0; r < kT; ++r) {
-                        const int off = off0 + r;
-                        const int sidx = lit ? ((t + off) & (kTile - 1)) : off;
-                        long long j = st + sidx;
-                        if (j >= N) j -= N;
-                        interact<T, kLog>(a, win[w][buf][(lit ? l : 0) + r], p.growth, i, (int)j, ev, ev_cap, ctr, step);
-                    }
-                } else {
-                    V2 F;
-                    F.x = a.fx; F.y = a.fy;
-#pragma unroll
-                    for (int r = 0; r < kT; ++r) F = F + term[r];
-                    a.fx = F.x; a.fy = F.y;
-                }
-                pairs += kT;
-            }
-        } else if (active) {
-            const int hi = off0 + kT < L ? off0 + kT : L;
-            for (int off = off0; off < hi; ++off) general_at(kk, st, L, off);
-            if (lit) {
-                if (hi > off0) pairs += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
-            } else {
-                for (int off = off0; off < hi; ++off) pairs += (st + off != i64) ? 1 : 0;
-            }
-        }
-        // (5) publish the state, then the sequence number (LDS operations of a wave execute in order)
-        if (tau + 1 < nturns) {
-            const int hp = (tau + 1) & 1;
-            hand_f[hp][l] = HandF{a.fx, a.fy};
-            hand_m[hp][l] = HandM{a.mnew, a.rnew, a.deleted, 0};
-            asm volatile("" ::: "memory");                 // ... and written before it: a wave's LDS operations
-            if (l == 0) *(volatile int*)&seq = tau + 1;    // execute in order, no wait is needed in between
-            __builtin_amdgcn_s_setprio(0);
-        } else if (mine) {                                 // the last turn of the walk: epilogue by this wave
-            const int q = i - lo;
-            const Vec2<T> v = Vown[q];
-            if (active) {
-                Rec<T> out; Vec2<T> vout;
-                finish_body<T>(a, v, p, out, vout);
-                S_J[q] = out;
-                S_V[q] = vout;
-            } else {   // frozen body: no thread exists for it in the reference, state carried over unchanged
-                S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri};
-                S_V[q] = v;
-            }
-        }
-        // the prefetched window of this wave's next turn
-        buf ^= 1;
-        st = st_next;
-        cur = check_window(issued_next, buf);
-    }
-    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
-    if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 }
 
 // ---------------------------------------------------------------------------------------------------------

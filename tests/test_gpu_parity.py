@@ -94,8 +94,8 @@ def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
                       **kw)
 
 
-# automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | pc8 | ring and its tuning forms (sleep, 4 waves, 16-position turns)
-VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 40, 50, 51, 52, 53, 54, 55, 56]
+# automatic | v1 | v3 K=1,2,4,8 | v3 256-thread | ring: 2x8, 4x4, 1x8 rings x waves per workgroup, 16-position turns
+VARIANTS = [0, 1, 11, 12, 14, 18, 31, 32, 50, 52, 53, 54]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -255,11 +255,12 @@ def test_extreme_values_take_the_general_path(nb, variant):
     st.close()
 
 
-@pytest.mark.parametrize("variant", [0, 11, 40])
+@pytest.mark.parametrize("variant", [0, 11, 50, 52])
 def test_unbounded_tile_mid_walk(nb, variant):
     """A tile with an out-of-range coordinate in the MIDDLE of every other body's walk (not in their own block):
     the fast path must hand exactly that tile to the general code and resume, for all kernels (this is the
-    non-fast-tile-between-fast-tiles path of the producer/consumer kernel)."""
+    non-fast-turn-between-fast-turns path of the ring kernel: with an unbounded body in the replica it scans
+    every window, Meta::summary)."""
     n = 4096
     cfg = nb.stock_config(particleCount=n, fieldWidth=30000, fieldHeight=30000)
     bodies = nb.init_bodies(cfg)
@@ -337,7 +338,8 @@ def test_more_ranks_than_work(nb, case):
 @pytest.mark.parametrize("world", [2, 8])
 def test_big_golden_n65536_sharded(nb, world):
     """The N=65536 stock-radii golden (10 095 deletions in one step) through a `world`-rank partition with the
-    AUTOMATIC kernel choice: 8 ranks own 8192 bodies each, which selects the producer/consumer kernel."""
+    AUTOMATIC kernel choice: 8 ranks own 8192 bodies each, which selects the ring kernel with one ring per workgroup
+    (2 ranks: 32768 each, two rings per workgroup)."""
     g = json.load(open(os.path.join(GOLD, "big_n65536.json")))["stock_radii"]
     cfg = nb.stock_config(particleCount=65536)
     grp = nb.StepperGroup(world, cfg=cfg)
@@ -356,8 +358,9 @@ def test_big_golden_n65536_sharded(nb, world):
 
 
 def test_headline_size_eight_ranks_equals_one(nb):
-    """BASELINE.json metric shape: N=262144 range-partitioned over 8 ranks (automatic kernel choice = the
-    producer/consumer kernel on 32768 own bodies) against the single-rank run, whole state, bit for bit."""
+    """BASELINE.json metric shape: N=262144 range-partitioned over 8 ranks (automatic kernel choice = the ring
+    kernel with 2 rings x 8 waves per workgroup on 32768 own bodies; 1 rank: 4 rings x 4 waves) against the
+    single-rank run, whole state, bit for bit."""
     cfg = nb.stock_config(particleCount=262144, minRadius=0.0, maxRadius=0.0)
     bodies = nb.init_bodies(cfg)
     grp = nb.StepperGroup(8, cfg=cfg)
@@ -377,15 +380,17 @@ def test_headline_size_eight_ranks_equals_one(nb):
 def test_c2_c3_thousand_steps_all_paths_agree(nb, radii):
     """BASELINE.json configs[1]/[2]: N=65536, 1000 steps, without and with collisions.  The oracle cannot run
     this horizon in test time; what is checked is (1) step 1 against the golden sha256 from the reference,
-    and (2) after all 1000 steps the automatic kernel, the producer/consumer kernel, the first-generation
-    kernel and a 4-rank range partition hold the same state bit for bit (they share no force code beyond the
-    pair function), with the survivor count shrinking through the kernel-selection and ragged-N regimes."""
+    and (2) after all 1000 steps the automatic kernel (ring), the one-lane-per-body kernel, the first-generation
+    kernel and a 4-rank range partition hold the same state bit for bit (three force kernels that share only the
+    pair function), with the survivor count shrinking through the kernel-selection and ragged-N regimes.
+    NOTE: beyond step 1 this is a CROSS-VARIANT check, not an oracle comparison - the oracle-anchored horizons are
+    100 steps at N=1024 and 1000 steps at N=2048 (tests/golden/steps_c1_n1024, steps_long_n2048)."""
     g = json.load(open(os.path.join(GOLD, "big_n65536.json")))["radii0" if radii == "radii0" else "stock_radii"]
     kw = {"minRadius": 0.0, "maxRadius": 0.0} if radii == "radii0" else {}
     cfg = nb.stock_config(particleCount=65536, **kw)
     bodies = nb.init_bodies(cfg)
     states = {}
-    for name, variant in (("auto", 0), ("pc8", 40), ("v1", 1)):
+    for name, variant in (("auto", 0), ("one-lane", 31), ("v1", 1)):
         st = nb.Stepper(cfg, kernel_variant=variant)
         st.upload(bodies)
         st.step(1)
@@ -410,8 +415,9 @@ def test_c2_c3_thousand_steps_all_paths_agree(nb, radii):
 
 def test_headline_hundred_steps_partitions_agree(nb):
     """BASELINE.json configs[3] shape over a longer horizon: N=262144, 100 steps, the 1-, 2- and 8-rank partitions
-    (three different kernel choices: 4-wave one-lane, 2-wave one-lane, producer/consumer) end in the same state
-    bit for bit, and the step-1 state was checked against the oracle by test_big/bench."""
+    (three different kernel shapes: ring 4x4, ring 4x4 on half the bodies, ring 2x8) end in the same state bit for
+    bit.  NOTE: a CROSS-PARTITION check anchored at step 1 (test_full_size_sampled_parity_n262144 and bench.py's
+    parity leg compare step 1 with the oracle); C4's own horizon is 1000 steps, 100 are run here."""
     cfg = nb.stock_config(particleCount=262144, minRadius=0.0, maxRadius=0.0)
     bodies = nb.init_bodies(cfg)
     outs = []
@@ -457,10 +463,11 @@ def test_ragged_large_n_sampled(nb, n):
     st.close()
 
 
-@pytest.mark.parametrize("precision,n", [(0, 1048576), (1, 131072)])
+@pytest.mark.parametrize("precision,n", [(0, 1048576), (1, 131072), (1, 1048576)])
 def test_max_size_sampled(nb, precision, n):
-    """configs[4] sizes: N = 1 Mi bodies (fp32: one step is 1.1e12 pairs) and a large fp64 case; the oracle on
-    spread samples of bodies, bit-exact."""
+    """configs[4] size: N = 1 Mi bodies in fp32 and in fp64 (C5 itself: 1.1e12 pairs per step, 48 MiB block,
+    include/vec2.h:6-17 layout) and a smaller fp64 case; the oracle on spread samples of bodies, bit-exact, and the
+    evaluated-pair count."""
     cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
     bodies = nb.init_bodies(cfg, precision)
     st = nb.Stepper(cfg, precision=precision)
@@ -475,6 +482,27 @@ def test_max_size_sampled(nb, precision, n):
         assert np.array_equal(bits(out.Velocities[lo:lo + 8]), bits(V))
     assert st.stats().pairs == ol.port().oracle_pairs_per_step(n, ol.LITERAL)
     st.close()
+
+
+def test_c5_shape_eight_ranks_equals_one(nb):
+    """BASELINE.json configs[4] (C5) as it is sharded: N = 1 048 576 bodies in fp64 range-partitioned over 8 ranks
+    (131 072 own bodies each, the fp64 production kernel) for 2 steps against the single-rank run, whole state, bit
+    for bit; fp64 has no reference at all, so the anchor is the fp64 oracle of test_max_size_sampled."""
+    n = 1048576
+    cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg, nb.F64)
+    grp = nb.StepperGroup(8, cfg=cfg, precision=nb.F64)
+    grp.upload(bodies)
+    assert [r.own_range()[1] for r in grp.ranks] == [131072] * 8
+    grp.step(2)
+    one = nb.Stepper(cfg, precision=nb.F64)
+    one.upload(bodies)
+    one.step(2)
+    a, b = grp.download(), one.download()
+    assert a.numBodies == b.numBodies
+    assert np.array_equal(bits(a.block), bits(b.block))
+    assert sum(r.stats().pairs for r in grp.ranks) == one.stats().pairs
+    grp.close(); one.close()
 
 
 def test_rccl_path_single_rank(nb):
@@ -617,20 +645,33 @@ def test_state_save_restore(nb, tmp_path):
     a.close(); b.close()
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:     # a port that is free right now
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_bench_distributed_control_path_one_rank():
     """bench.py exactly as the driver launches it for N>1 (torch.distributed.run, gloo rendezvous on 127.0.0.1,
-    communicator id broadcast, RCCL slot all-gather), rehearsed with ONE rank because the box has one GPU."""
+    communicator id broadcast, RCCL slot all-gather, collective download, self-check against a single-rank run),
+    rehearsed with ONE rank because the box has one GPU.  tests/test_gpu_multirank.py runs it with two ranks where
+    two GPUs are visible."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
-           "--warmup", "1", "--bodies", "16384", "--force-comm", "--no-cpu-baseline"]
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2",
+           "--warmup", "1", "--bodies", "16384", "--stock-radii", "--force-comm", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["roofline"]["kernel_ms"] > 0
+    assert d["parity_rccl_path"]["bitwise_equal"] is True, d["parity_rccl_path"]
+    assert d["parity_rccl_path"]["bodies_after"] < 16384          # deletions happened: the slots were ragged
+    assert abs(d["roofline"]["algorithmic_bytes_per_launch"] - 48 * 16384) <= 48 * 2000   # 48 B per body (fp32)
+    assert 0 < d["roofline"]["valu"]["frac"] < 1
 
 
 def test_cli_matches_oracle(nb, tmp_path):
