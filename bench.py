@@ -87,7 +87,7 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
                       (lo, lo + count, n, st.pairs, t, threads)}
     # the same restatement on ONE thread, about two seconds of it
     ol.port().oracle_set_threads(1)
-    one = max(8, min(count, int(2.0 * rate / threads / per_body)))
+    one = max(8, min(count, int(10.0 * rate / threads / per_body)))   # ~2 s: one thread is faster than rate / threads
     t0 = time.perf_counter()
     *_, st1 = ol.port_range(blk, n, lo, lo + one, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
     t1 = time.perf_counter() - t0
