@@ -11,6 +11,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PORT_SO = os.path.join(ROOT, "oracle", "_build", "libnbody_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libnbody_ref.so")
+REF_FMA_SO = os.path.join(ROOT, "oracle", "_ref", "libnbody_ref_fma.so")   # g++ -ffp-contract=fast -mfma build
 
 LITERAL, CLEAN = 0, 1
 
@@ -62,6 +63,27 @@ def port():
 
 def have_ref():
     return os.path.exists(REF_SO)
+
+
+_ref_fma = None
+
+
+def ref_fma():
+    """The FMA-contracted build of the literal shim (fixture generation only)."""
+    global _ref_fma
+    if _ref_fma is None:
+        L = ctypes.CDLL(REF_FMA_SO)
+        L.ref_step.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_float, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+        _ref_fma = L
+    return _ref_fma
+
+
+def ref_fma_step(block, n, dt, fw, fh, growth, pre=False):
+    cn = ctypes.c_int(n)
+    preb = np.empty(6 * n, dtype=np.float32) if pre else None
+    ref_fma().ref_step(block.ctypes.data, ctypes.byref(cn), dt, fw, fh, growth, preb.ctypes.data if pre else None)
+    return cn.value, preb
 
 
 def ref():

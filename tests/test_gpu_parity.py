@@ -120,6 +120,69 @@ def test_golden_free_run(nb, path, variant):
     st.close()
 
 
+def _rel(a, b, scale=None):
+    scale = float(np.abs(np.asarray(b, np.float64)).max()) if scale is None else scale
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(scale, 1e-300))
+
+
+def test_bounded_against_fma_contracted_build(nb):
+    """The other plausible compile of the reference (`nvcc -O3`, cudaCmd.txt:1: -fmad=true would contract
+    src/nbody.cu:131,232,239,288 and include/vec2f.h:91-93 into FMAs).  tests/golden/fma_pairs.npz holds teacher-forced
+    pairs S_t -> S_t+1 from an FMA-contracted build of the reference's kernel text.  The HIP path (no contraction,
+    bit-identical to the oracle of record) loads S_t, steps ONCE and must be within the north_star tolerance of that
+    build - max|dP|/max|P| and max|dV|/max|V| <= 1e-5 - with IDENTICAL collision outcomes: survivor count, deleted set
+    D_t, and bit-identical masses (same absorb set E_t: a body's new mass is the ordered sum of what it absorbed).
+    Measured margin: 2e-7 at worst, printed below."""
+    z = np.load(os.path.join(GOLD, "fma_pairs.npz"))
+    dt, growth, fw, fh = z["params"]
+    worst = {}
+    for key in [k[:-3] for k in z.files if k.endswith("_in")]:
+        n0, n1 = (int(v) for v in z[key + "_n"])
+        st = _stepper(nb, n0, int(fw), int(fh), np.float32(dt), np.float32(growth), record_events=True)
+        st.upload(nb.BodiesData.from_block(z[key + "_in"].view(np.float32), n0))
+        st.step(1)
+        out = st.download()
+        ev = st.events()
+        st.close()
+        fP, fV, fM, fR = ol.carve(z[key + "_pre"].view(np.float32), n0)
+        keep = fM != 0
+        assert out.numBodies == n1 == int(keep.sum()), key
+        assert np.array_equal(np.unique(ev["i"][ev["kind"] == 1]), np.nonzero(~keep)[0]), key        # D_t
+        assert np.array_equal(bits(out.Masses), bits(fM[keep])), key                                   # same E_t
+        worst[key] = (_rel(out.Positions, fP[keep]), _rel(out.Velocities, fV[keep]), _rel(out.Radii, fR[keep]))
+        assert worst[key][0] <= 1e-5 and worst[key][1] <= 1e-5 and worst[key][2] <= 1e-6, (key, worst[key])
+    for key in ("n65536_stock", "n65536_r0"):                          # C3 / C2 shapes, step 1
+        n0, n1 = (int(v) for v in z[key + "_n"])
+        min_r, max_r = (float(v) for v in z[key + "_kw"])
+        cfg = nb.stock_config(particleCount=n0, minRadius=min_r, maxRadius=max_r)
+        st = nb.Stepper(cfg, record_events=True, event_capacity=1 << 22)
+        st.upload(nb.init_bodies(cfg))
+        st.step(1)
+        out = st.download()
+        ev = st.events(cap=1 << 22)
+        st.close()
+        deleted = np.unique(ev["i"][ev["kind"] == 1]).astype(np.int64)
+        assert out.numBodies == n1, key
+        assert np.array_equal(deleted, z[key + "_deleted"]), key                                       # D_t
+        pre_m = np.zeros(n0, np.float32)                               # pre-compaction masses: 0 where deleted
+        alive = np.ones(n0, bool)
+        alive[deleted] = False
+        pre_m[alive] = out.Masses
+        assert hashlib.sha256(pre_m.tobytes()).digest() == z[key + "_mass_sha256"].tobytes(), key      # same E_t
+        idx = z[key + "_idx"].astype(np.int64)
+        idx = idx[alive[idx]]
+        sel = np.isin(z[key + "_idx"], idx)
+        post = idx - np.searchsorted(deleted, idx)
+        maxP, maxV = z[key + "_maxabs"]
+        worst[key] = (_rel(out.Positions[post], z[key + "_P"].view(np.float32)[sel], maxP),
+                      _rel(out.Velocities[post], z[key + "_V"].view(np.float32)[sel], maxV),
+                      _rel(out.Radii[post], z[key + "_R"].view(np.float32)[sel], 200.0))
+        assert worst[key][0] <= 1e-5 and worst[key][1] <= 1e-5 and worst[key][2] <= 1e-6, (key, worst[key])
+    print("\nHIP path vs FMA-contracted build, one step, (rel dP, rel dV, rel dR):",
+          {k: tuple("%.1e" % v for v in w) for k, w in worst.items()})
+    assert max(max(w[:2]) for w in worst.values()) < 1e-6
+
+
 def test_golden_multi_step_enqueue(nb):
     """100 steps enqueued in one call (no host synchronisation in between) = C1 of BASELINE.json."""
     z = np.load(os.path.join(GOLD, "steps_c1_n1024.npz"))
