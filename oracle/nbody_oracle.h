@@ -8,11 +8,14 @@
  *   host compaction        /root/reference/src/nbody.cu:488-510
  *   Vec2f rounding order   /root/reference/include/vec2f.h:45-93
  *
- * Pinning: the reference holds no tests or golden vectors.  This restatement is pinned
- * against the reference ITSELF: oracle/_ref/libnbody_ref.so runs the reference's own kernel text on the CPU
- * (oracle/ref_shim), tests/golden/ holds vectors generated from it (tests/golden/make_golden.py), and
- * tests/test_oracle_cpu.py checks bit-equality of this file against both.  The fp64 variant has no
- * reference at all (the reference has no fp64 kernel): "parity unpinned" for fp64.
+ * PARITY UNPINNED: the reference holds no tests, fixtures or golden vectors, its stepper exists only as
+ * CUDA kernels, and this image has no nvcc.  The nearest witness: oracle/_ref/libnbody_ref.so runs the reference's own
+ * kernel text on the CPU behind stand-ins for the CUDA headers and runtime (oracle/ref_shim) - which, needing those
+ * stand-ins, pins nothing in the strict sense; tests/golden/ holds vectors generated from it
+ * (tests/golden/make_golden.py) and tests/test_oracle_cpu.py checks bit-equality of this file against both.  The FP
+ * model (no contraction) is our choice; the other plausible one (nvcc's default FMA contraction) is bounded by
+ * tests/golden/fma_pairs.npz (<= 2e-7 per step, identical collision outcomes).  The fp64 variant has no reference at
+ * all (the reference has no fp64 kernel).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */

@@ -61,7 +61,7 @@ int main() {
     if (run<128, 8448>(512, "v3 K=1, G=4 shape")) return 1;
     if (run<256, 8448>(512, "256-thread WGs, 2048 waves")) return 1;
     if (run<256, 8448>(256, "256-thread WGs, 1024 waves")) return 1;
-    if (run<512, 73880>(512, "pc8 shape, G=8")) return 1;
-    if (run<512, 73880>(1024, "pc8 shape, G=4")) return 1;
+    if (run<512, 73880>(512, "8-wave workgroups, G=8")) return 1;
+    if (run<512, 73880>(1024, "8-wave workgroups, G=4")) return 1;
     return 0;
 }

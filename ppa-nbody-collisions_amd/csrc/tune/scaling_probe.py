@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 import ppa_nbody_collisions_amd as nb  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 11, 32, 40, 50]
+variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 31, 50, 52, 54]
 cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
 bodies = nb.init_bodies(cfg)
 print("N=%d radii 0; per-rank force kernel ms per step and the implied whole-job pairs/s" % n)
