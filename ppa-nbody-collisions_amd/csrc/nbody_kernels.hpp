@@ -806,6 +806,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     long long st = tile_start_slow(w / kTurnsPerTile);
     int buf = 0;
     int flags_in = 0;                                      // `flags` of the last record this wave received
+    int plain_turns = 0;                                   // turns of this wave that took the common path
     // {mnew, rnew, deleted} are only needed by the general code and the epilogue: brought up to date from the last
     // received flags (and the rare record) right before those, never on the fast path
     auto sync_rare = [&]() {
@@ -848,6 +849,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             const Rec<T>* walk = &win[w][buf][lit ? l : 0];
             V2 own;
             own.x = a.xi; own.y = a.yi;
+            float closest = kFastHi;                       // zero-radius path: the smallest d2 of the turn, per lane
             auto evaluate = [&](auto r0_tag) {
                 constexpr bool kR0 = decltype(r0_tag)::value;
                 constexpr int kG = (kR0 && kT <= 16) ? 8 : 4;   // reads per batch: the terms already take 2 kT VGPRs
@@ -874,14 +876,23 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                             rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
                             q = __builtin_elementwise_fma(rs, rs, q);          // flag only
                         }
-                        const unsigned long long close_a = le_mask(d2.x, q.x);
-                        flag |= (r0 + u == 0 && first) ? 0ull : close_a;
-                        flag |= le_mask(d2.y, q.y);
+                        if (kR0) {
+                            // all radii +0: the threshold is 2^-80 for every pair, so ONE comparison of the turn's
+                            // smallest d2 decides (half an instruction per pair; d2 is finite here - the coordinates
+                            // are bounded - so no NaN can hide in the minimum)
+                            const float da2 = (r0 + u == 0 && first) ? kFastHi : d2.x;
+                            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(da2), "v"(d2.y));
+                        } else {
+                            const unsigned long long close_a = le_mask(d2.x, q.x);
+                            flag |= (r0 + u == 0 && first) ? 0ull : close_a;
+                            flag |= le_mask(d2.y, q.y);
+                        }
                         const V2 inv = fast_inv_cube2(d2);
                         term[r0 + u] = (da * ba.m) * inv.x;
                         term[r0 + u + 1] = (db * bb.m) * inv.y;
                     }
                 }
+                if (kR0) flag = le_mask(closest, kFastLo);
             };
             if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
             else evaluate(std::false_type{});
@@ -925,7 +936,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, flags_in};
             __builtin_amdgcn_s_setprio(0);
             a.fx = fx; a.fy = fy;
-            if (active) pairs += kT - (first ? 1 : 0);
+            plain_turns += 1;                              // a scalar: kT pairs per active lane, added up at the end
+            if (first && active) pairs -= 1;
         } else {
             a.fx = __int_as_float(h.x); a.fy = __int_as_float(h.y);
             sync_rare();
@@ -1000,6 +1012,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             S_V[q] = v;
         }
     }
+    if (active) pairs += (unsigned long long)plain_turns * kT;
     if (timeouts != 0 && l == 0) atomicAdd(&ctr->errors, (unsigned long long)timeouts);
     for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
     if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
