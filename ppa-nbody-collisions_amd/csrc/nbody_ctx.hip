@@ -221,7 +221,20 @@ void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblock
         else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
         return;
     }
-    const int grid = (nblocks + 1) / 2;                    // two 128-lane groups per workgroup
+    // Two forms of the same kernel text.  256-thread workgroups (two independent 128-lane groups) overlap best and are
+    // the default (8.9e11 pairs/s at N = 1 048 576).  512-thread workgroups (four groups, one per-tile barrier: the two
+    // waves of every SIMD in lock step) are 6 % slower in steady state but immune to the arbiter's older-wave-first
+    // rule, which costs the 256-thread form 8 % when a launch is exactly ONE round of two workgroups per CU - C5's
+    // 8-rank shape, 131 072 own bodies: 164.0 vs 168.6 ms, same box.  So: the 512-thread form when the 256-thread form
+    // would need between one and two workgroups per CU, the 256-thread form otherwise.  kernel_variant 31 / 33 force them.
+    const bool one_uneven_round = c->own_upper > 256 * 2 * kTile && c->own_upper <= 512 * 2 * kTile;
+    if (c->desc.kernel_variant == 33 || (c->desc.kernel_variant != 31 && one_uneven_round)) {
+        const int grid = (nblocks + 3) / 4;
+        if (log) hipLaunchKernelGGL((forces_v3q_f64<true>), dim3(grid), dim3(4 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
+        else hipLaunchKernelGGL((forces_v3q_f64<false>), dim3(grid), dim3(4 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
+        return;
+    }
+    const int grid = (nblocks + 1) / 2;
     if (log) hipLaunchKernelGGL((forces_v3w_f64<true>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
     else hipLaunchKernelGGL((forces_v3w_f64<false>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
 }
@@ -880,7 +893,10 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const fl
 
 const char* nbody_force_kernel_name(nbody_ctx* c) {
     if (!c) return "";
-    if (c->desc.precision == NBODY_F64) return c->desc.kernel_variant == 1 ? "forces_v1<double>" : "forces_v3w_f64";
+    if (c->desc.precision == NBODY_F64)
+        return c->desc.kernel_variant == 1 ? "forces_v1<double>"
+               : (c->desc.kernel_variant == 33 || (c->desc.kernel_variant != 31 && c->own_upper > 65536 && c->own_upper <= 131072))
+                     ? "forces_v3q_f64 (512-thread workgroups)" : "forces_v3w_f64";
     switch (c->desc.kernel_variant) {
         case 1: return "forces_v1<float>";
         case 11: case 12: case 14: case 18: return "forces_v3_f32";

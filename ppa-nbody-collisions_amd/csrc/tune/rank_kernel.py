@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Profiling probe: ONE rank's force kernel of a G-rank partition of N bodies, launched `reps` times back to back
 on one GPU in steady state (nbody_debug_force_only).  Also the target of the rocprofv3 counter passes.
-    python3 rank_kernel.py N G rank variant reps [stock]"""
+    python3 rank_kernel.py N G rank variant reps [stock|r0] [fp64]"""
 import os
 import sys
 
@@ -13,8 +13,9 @@ import ppa_nbody_collisions_amd as nb  # noqa: E402
 n, world, rank, variant, reps = (int(v) for v in sys.argv[1:6])
 kw = {} if (len(sys.argv) > 6 and sys.argv[6] == "stock") else {"minRadius": 0.0, "maxRadius": 0.0}
 cfg = nb.stock_config(particleCount=n, **kw)
-st = nb.Stepper(cfg, rank=rank, world=world, group=world > 1, kernel_variant=variant)
-st.upload(nb.init_bodies(cfg))
+precision = nb.F64 if "fp64" in sys.argv[6:] else nb.F32
+st = nb.Stepper(cfg, precision=precision, rank=rank, world=world, group=world > 1, kernel_variant=variant)
+st.upload(nb.init_bodies(cfg, precision))
 st.force_only(3)
 st.sync()
 s0 = st.stats()
