@@ -120,6 +120,7 @@ struct nbody_ctx {
     Counters* h_counters = nullptr;
     Counters* h_counters_async = nullptr;   // pinned; refreshed like h_meta_async (nbody_step looks at .errors)
     int spin_limit = 1 << 24;       // ring kernel: polls before a hand-off wait is declared failed
+    int num_cus = 256;              // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     bool device_failed = false;     // sticky until the next nbody_upload: a kernel reported a failed hand-off wait
     int n_upper = 0;            // host-side upper bound of the global count (exact after a sync)
     int own_upper = 0;          // upper bound of the own count
@@ -159,6 +160,7 @@ StepParams<T> make_params(const nbody_ctx_desc& d, int spin_limit = 1 << 24) {
     p.wall_lo_y = (T)(-d.fieldHeight);
     p.literal = d.semantics == NBODY_LITERAL;
     p.spin_limit = spin_limit;
+    p.rotate_priority = 0;
     return p;
 }
 
@@ -221,22 +223,17 @@ void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblock
         else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
         return;
     }
-    // Two forms of the same kernel text.  256-thread workgroups (two independent 128-lane groups) overlap best and are
-    // the default (8.9e11 pairs/s at N = 1 048 576).  512-thread workgroups (four groups, one per-tile barrier: the two
-    // waves of every SIMD in lock step) are 6 % slower in steady state but immune to the arbiter's older-wave-first
-    // rule, which costs the 256-thread form 8 % when a launch is exactly ONE round of two workgroups per CU - C5's
-    // 8-rank shape, 131 072 own bodies: 164.0 vs 168.6 ms, same box.  So: the 512-thread form when the 256-thread form
-    // would need between one and two workgroups per CU, the 256-thread form otherwise.  kernel_variant 31 / 33 force them.
-    const bool one_uneven_round = c->own_upper > 256 * 2 * kTile && c->own_upper <= 512 * 2 * kTile;
-    if (c->desc.kernel_variant == 33 || (c->desc.kernel_variant != 31 && one_uneven_round)) {
-        const int grid = (nblocks + 3) / 4;
-        if (log) hipLaunchKernelGGL((forces_v3q_f64<true>), dim3(grid), dim3(4 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
-        else hipLaunchKernelGGL((forces_v3q_f64<false>), dim3(grid), dim3(4 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
-        return;
-    }
-    const int grid = (nblocks + 1) / 2;
-    if (log) hipLaunchKernelGGL((forces_v3w_f64<true>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
-    else hipLaunchKernelGGL((forces_v3w_f64<false>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(double));
+    const int grid = (nblocks + 1) / 2;                    // two 128-lane groups per workgroup
+    // priority rotation (nbody_forces_v3.inc) only when every workgroup of the launch is resident at once: 168 VGPRs
+    // = 3 waves per SIMD = 3 of these 4-wave workgroups per CU
+    StepParams<double> pr = p;
+    pr.rotate_priority = grid <= 3 * c->num_cus;
+#define NB_FORCES_ARGS_PR                                                                                  \
+    (const Rec<double>*)c->J, (const Vec2<double>*)c->Vown, (Rec<double>*)c->S_J, (Vec2<double>*)c->S_V,    \
+        (const Meta*)c->meta, pr, c->events, c->ev_cap, c->counters
+    if (log) hipLaunchKernelGGL((forces_v3w_f64<true>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS_PR);
+    else hipLaunchKernelGGL((forces_v3w_f64<false>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS_PR);
+#undef NB_FORCES_ARGS_PR
 }
 
 template <int K>
@@ -441,6 +438,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     c->desc = *d;
     c->desc.comm_id = nullptr;
     c->spin_limit = ring_spin_limit();
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->real_bytes = d->precision == NBODY_F64 ? 8 : 4;
     c->rec_bytes = 4 * c->real_bytes;
     c->cap = d->capacity;
@@ -894,9 +892,7 @@ int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updM, const fl
 const char* nbody_force_kernel_name(nbody_ctx* c) {
     if (!c) return "";
     if (c->desc.precision == NBODY_F64)
-        return c->desc.kernel_variant == 1 ? "forces_v1<double>"
-               : (c->desc.kernel_variant == 33 || (c->desc.kernel_variant != 31 && c->own_upper > 65536 && c->own_upper <= 131072))
-                     ? "forces_v3q_f64 (512-thread workgroups)" : "forces_v3w_f64";
+        return c->desc.kernel_variant == 1 ? "forces_v1<double>" : "forces_v3w_f64";
     switch (c->desc.kernel_variant) {
         case 1: return "forces_v1<float>";
         case 11: case 12: case 14: case 18: return "forces_v3_f32";

@@ -70,6 +70,7 @@ struct StepParams {
     T wall_hi_y, wall_lo_y;
     int literal;              // 1: reference index semantics, 0: clean all-pairs
     int spin_limit;           // ring kernel: polls of a hand-off record before the wait is declared failed
+    int rotate_priority;      // one-lane kernels built with NB_V3_ROTATE_PRIORITY: the launch is a single round
 };
 
 template <typename T> __device__ __forceinline__ T ieee_sqrt(T x);
@@ -490,6 +491,7 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 
 // The same kernel in fp64 (256-thread form, one lane per body): the fp64 production kernel.  A record is 32 bytes,
 // 8 reads per batch (same-box A/B: 4 reads with the 4-waves register budget -0.4 %, 16 reads -4 %).
+#define NB_V3_ROTATE_PRIORITY
 #define NB_V3_REAL double
 #define NB_V3_SIGNATURE                                                                                      \
     template <bool kLog>                                                                                     \
@@ -517,52 +519,7 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
     for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
     if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 #include "nbody_forces_v3.inc"
-#undef NB_V3_REAL
-#undef NB_V3_SIGNATURE
-#undef NB_V3_LDS
-#undef NB_V3_LANE
-#undef NB_V3_WG
-#undef NB_V3_BATCH
-#undef NB_V3_CONSTANTS
-#undef NB_V3_RANGE
-#undef NB_V3_REC
-#undef NB_V3_VEL
-#undef NB_V3_PUT
-#undef NB_V3_KEEP
-#undef NB_V3_COUNT
-
-// The fp64 kernel with 512-thread workgroups: FOUR independent 128-lane groups share a workgroup and its per-tile
-// barrier.  Eight waves = two per SIMD = the whole CU at this kernel's 168 VGPRs, so the two waves of a SIMD are in
-// lock step by construction.  With two 256-thread workgroups per CU instead, the arbiter's older-wave-first rule lets
-// the older workgroup run ahead and the CU finishes the launch half empty: 175.7 vs 150.7 ms ideal at C5's 8-rank
-// shape (131 072 own bodies of 1 048 576, exactly two such workgroups per CU).
-#define NB_V3_REAL double
-#define NB_V3_SIGNATURE                                                                                      \
-    template <bool kLog>                                                                                     \
-    __global__ __launch_bounds__(4 * kTile, 2) void forces_v3q_f64(                                          \
-        const Rec<double>* __restrict__ J, const Vec2<double>* __restrict__ Vown,                            \
-        Rec<double>* __restrict__ S_J, Vec2<double>* __restrict__ S_V, const Meta* __restrict__ meta,        \
-        StepParams<double> p, Event* ev, int ev_cap, Counters* ctr)
-#define NB_V3_LDS                                                                                            \
-    __shared__ Rec<T> tile_all[4][2][2 * kTile];                                                             \
-    __shared__ int tile_bad_all[4][2][kTile / kWave];                                                        \
-    __shared__ int tile_rnz_all[4][2][kTile / kWave];                                                        \
-    Rec<T>(&tile)[2][2 * kTile] = tile_all[threadIdx.x / kTile];                                             \
-    int(&tile_bad)[2][kTile / kWave] = tile_bad_all[threadIdx.x / kTile];                                    \
-    int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
-#define NB_V3_LANE const int lane = threadIdx.x % kTile;
-#define NB_V3_WG const int wg = blockIdx.x * 4 + threadIdx.x / kTile;
-#define NB_V3_BATCH 8
-#define NB_V3_CONSTANTS constexpr int K = 1;
-#define NB_V3_RANGE const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
-#define NB_V3_REC(j) J[j]
-#define NB_V3_VEL(i) Vown[i - lo]
-#define NB_V3_PUT(q, i, out, vout) S_J[q] = out; S_V[q] = vout;
-#define NB_V3_KEEP(q, i, a, v) S_J[q] = Rec<T>{a.xi, a.yi, a.mi, a.ri}; S_V[q] = v;
-#define NB_V3_COUNT(pairs)                                                                                   \
-    for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);                      \
-    if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
-#include "nbody_forces_v3.inc"
+#undef NB_V3_ROTATE_PRIORITY
 #undef NB_V3_REAL
 #undef NB_V3_SIGNATURE
 #undef NB_V3_LDS

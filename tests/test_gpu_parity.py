@@ -870,7 +870,7 @@ def test_error_paths(nb):
     st.close(); st2.close()
 
 
-@pytest.mark.parametrize("variant", [0, 33, 1], ids=["production-kernel", "512-thread-form", "general-kernel"])
+@pytest.mark.parametrize("variant", [0, 1], ids=["production-kernel", "general-kernel"])
 @pytest.mark.parametrize("n,field,max_r", [(1500, 6000, 200.0), (4096, 100000, 200.0), (5000, 100000, 0.0)])
 def test_fp64_matches_oracle(nb, n, field, max_r, variant):
     """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); both fp64 kernels
