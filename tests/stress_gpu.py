@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""GPU soak (a script, not collected by pytest): seeded random cases through the ring kernel's workgroup shapes and the
+one-lane kernels - N up to 30000, dense and sparse fields, radii 0 and not, literal and clean semantics, 1..8 ranks on
+one GPU - every step compared bit for bit with the CPU oracle.  Hunts for rare hand-off / window / re-partition bugs that
+the fixed test cases cannot see.     python tests/stress_gpu.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: F401,E402
+import ppa_nbody_collisions_amd as nb  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+
+VARIANTS = [0, 0, 50, 52, 53, 54, 31, 11]
+DT, GROWTH = np.float32(0.2), np.float32(0.1)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+t0 = time.time()
+cases = fails = 0
+while time.time() - t0 < budget:
+    n = int(rng.choice([rng.integers(130, 700), rng.integers(700, 5000), rng.integers(5000, 30000)]))
+    field = int(rng.choice([2000, 20000, 100000]))
+    min_r = float(rng.choice([0.0, 0.0, 5.0, 50.0]))
+    max_r = min_r + (0.0 if min_r == 0.0 else float(rng.choice([0.0, 20.0, 150.0])))
+    max_m = float(rng.choice([1e5, 1e12, 1e17]))
+    sem = int(rng.integers(0, 4) == 0)
+    variant = int(rng.choice(VARIANTS))
+    world = int(rng.choice([1, 1, 2, 3, 5, 8]))
+    steps = int(rng.integers(2, 7))
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=min_r, maxRadius=max_r,
+                          maxRandBodyMass=max_m)
+    bodies = nb.init_bodies(cfg)
+    bodies.Velocities[:] = rng.uniform(-50, 50, size=(n, 2)).astype(np.float32)
+    if rng.integers(0, 3) == 0:                      # a few coincident bodies: collisions even at radius 0
+        k = int(rng.integers(1, 6))
+        src, dst = rng.integers(0, n, k), rng.integers(0, n, k)
+        bodies.Positions[dst] = bodies.Positions[src]
+    grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant)
+    grp.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    for s in range(steps):
+        grp.step(1)
+        cur, *_ = ol.port_step(blk, cur, DT, field, field, GROWTH, semantics=sem, want_events=False)
+        out = grp.download()
+        if not (out.numBodies == cur and np.array_equal(out.block.view(np.uint32), blk[:6 * cur].view(np.uint32))):
+            fails += 1
+            print("FAIL case %d step %d: n=%d field=%d r=[%g,%g] m=%g sem=%d variant=%d world=%d: got n=%d want %d" %
+                  (cases, s, n, field, min_r, max_r, max_m, sem, variant, world, out.numBodies, cur), flush=True)
+            break
+        if cur == 0:
+            break
+    grp.close()
+    cases += 1
+    if cases % 25 == 0:
+        print("%d cases, %d failures, %.0f s" % (cases, fails, time.time() - t0), flush=True)
+print("stress done: %d cases, %d failures, %.0f s" % (cases, fails, time.time() - t0), flush=True)
+sys.exit(1 if fails else 0)
