@@ -124,6 +124,33 @@ def parity_of_ranks(nb, st, bodies, cfg, precision, device, total_steps, rank):
     return out
 
 
+def reference_kernels_on_gpu(nb, bodies, cfg, our_ms_per_step, steps=2):
+    """The reference's OWN kernels on this GPU, as a baseline next to the CPU one: oracle/_ref/libnbody_ref_hip.so is the
+    reference's device code (src/nbody.cu:126-292) compiled unmodified by hipcc for gfx950 (oracle/ref_hip, built where
+    /root/reference exists) and launched with the reference's geometry.  Timed: ComputeForces + MoveBodies with HIP
+    events, i.e. WITHOUT the reference loop's per-step cudaMalloc / PCIe round trip / host compaction.  fp32 only (the
+    reference has no fp64 kernel).  Checker / baseline only, after the timed region; absent library -> None."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+    if bodies.precision != nb.F32 or not ol.have_ref_hip():
+        return None
+    n = bodies.numBodies
+    blk = bodies.contiguousData.copy()
+    pairs = 0
+    cur = n
+    total_ms = 0.0
+    for _ in range(steps):
+        pairs += ol.port().oracle_pairs_per_step(cur, ol.LITERAL)
+        cur, ms, _ = ol.ref_hip_run(blk, cur, 1, np.float32(cfg.timestep), cfg.fieldWidth, cfg.fieldHeight,
+                                    np.float32(cfg.growthRate))
+        total_ms += ms
+    return {"what": "the reference's ComputeForces + MoveBodies (src/nbody.cu:139-292), compiled unmodified by hipcc "
+                    "-O3 for gfx950, its own launch geometry, kernel time only, first %d steps of this workload" % steps,
+            "ms_per_step": total_ms / steps, "value": pairs / (total_ms * 1e-3), "unit": "body-pair-interactions/sec",
+            "this_framework_ms_per_step": our_ms_per_step, "speedup": (total_ms / steps) / our_ms_per_step}
+
+
 def parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR):
     """The second half of BASELINE.json's metric ("max-|dpos| vs ref"): the HIP path's state after step 1
     against the oracle's for the bodies the CPU leg just computed (outside the timed region).  The device
@@ -296,6 +323,9 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
+            ref_gpu = reference_kernels_on_gpu(nb, bodies, cfg, out["ms_per_step"])
+            if ref_gpu is not None:
+                out["reference_kernels_on_this_gpu"] = ref_gpu
     if (world > 1 or a.force_comm) and not a.no_parity:
         # every rank takes part (the download is a collective); rank 0 compares and reports
         par = parity_of_ranks(nb, st, bodies, cfg, precision, local_rank, a.warmup + a.steps, rank)

@@ -8,14 +8,13 @@
  *   host compaction        /root/reference/src/nbody.cu:488-510
  *   Vec2f rounding order   /root/reference/include/vec2f.h:45-93
  *
- * PARITY UNPINNED: the reference holds no tests, fixtures or golden vectors, its stepper exists only as
- * CUDA kernels, and this image has no nvcc.  The nearest witness: oracle/_ref/libnbody_ref.so runs the reference's own
- * kernel text on the CPU behind stand-ins for the CUDA headers and runtime (oracle/ref_shim) - which, needing those
- * stand-ins, pins nothing in the strict sense; tests/golden/ holds vectors generated from it
- * (tests/golden/make_golden.py) and tests/test_oracle_cpu.py checks bit-equality of this file against both.  The FP
- * model (no contraction) is our choice; the other plausible one (nvcc's default FMA contraction) is bounded by
- * tests/golden/fma_pairs.npz (<= 2e-7 per step, identical collision outcomes).  The fp64 variant has no reference at
- * all (the reference has no fp64 kernel).
+ * Pinning: the reference holds no tests, fixtures or golden vectors and this image has no nvcc.  What
+ * pins this restatement is the reference's OWN device code: oracle/_ref/libnbody_ref_hip.so compiles it unmodified with
+ * hipcc and runs it on the MI355X (oracle/ref_hip; tests/test_gpu_reference_kernels.py: bit-identical to this file and
+ * to the product up to N = 262144), and oracle/_ref/libnbody_ref.so runs the same text on the CPU behind a shim for the
+ * CUDA execution model (oracle/ref_shim; generated tests/golden/; bit-identical too).  The FP model (no contraction) is
+ * our choice; the other plausible one (default FMA contraction) is bounded: <= 4.3e-7 per step, identical collision
+ * outcomes.  The fp64 variant has no reference at all (the reference has no fp64 kernel): parity unpinned for fp64.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */

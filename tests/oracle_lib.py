@@ -65,6 +65,37 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+REF_HIP_SO = os.path.join(ROOT, "oracle", "_ref", "libnbody_ref_hip.so")          # the reference's kernels, hipcc, no contraction
+REF_HIP_FMA_SO = os.path.join(ROOT, "oracle", "_ref", "libnbody_ref_hip_fma.so")  # ... hipcc's default contraction
+_ref_hip = {}
+
+
+def have_ref_hip():
+    return os.path.exists(REF_HIP_SO) and os.path.exists(REF_HIP_FMA_SO)
+
+
+def ref_hip_run(block, n, steps, dt, fw, fh, growth, fma=False, pre=False):
+    """`steps` iterations of the reference's own kernels ON THE GPU (oracle/ref_hip).  block: float32[>= 6n], updated in
+    place.  Returns (new_n, kernel_ms_total, pre_compaction_block_of_last_step | None)."""
+    path = REF_HIP_FMA_SO if fma else REF_HIP_SO
+    if path not in _ref_hip:
+        L = ctypes.CDLL(path)
+        L.refhip_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float,
+                                 ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                                 ctypes.POINTER(ctypes.c_double)]
+        L.refhip_last_error.restype = ctypes.c_char_p
+        _ref_hip[path] = L
+    L = _ref_hip[path]
+    cn = ctypes.c_int(n)
+    ms = ctypes.c_double(0.0)
+    preb = np.empty(6 * n, dtype=np.float32) if pre else None
+    rc = L.refhip_run(block.ctypes.data, ctypes.byref(cn), steps, dt, fw, fh, growth,
+                      preb.ctypes.data if pre else None, ctypes.byref(ms))
+    if rc != 0:
+        raise RuntimeError("refhip_run failed (%d): %s" % (rc, L.refhip_last_error().decode()))
+    return cn.value, ms.value, preb
+
+
 _ref_fma = None
 
 

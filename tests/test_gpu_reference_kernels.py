@@ -1,0 +1,123 @@
+"""The product against THE REFERENCE'S OWN KERNELS run on the same GPU (run with -m gpu; needs oracle/_ref/libnbody_ref_hip*.so,
+built where /root/reference exists by `make -C oracle ref` and shipped to the GPU box with the tree).
+
+oracle/ref_hip compiles the reference's device code (src/nbody.cu:126-292, its #defines :35-37, its vec2f.h) UNMODIFIED with
+hipcc for gfx950 and launches it with the reference's own geometry and shared-memory size: real thread blocks, real
+barriers, nothing of CUDA stood in for.  Two builds:
+  * -ffp-contract=off : one rounding per written operation.  The product must match it BIT FOR BIT, at every size.
+  * hipcc's default contraction (the FMA reading; nvcc -O3's default too, cudaCmd.txt:1): the product must stay within the
+    north_star tolerance of it, 1e-5 relative per step, with identical collision outcomes.
+This is the strongest pin of parity available in this image: the reference's kernel text, executed by the hardware the
+product runs on, against the product, on the full benchmark configurations."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ol.have_ref_hip(), reason="oracle/_ref/libnbody_ref_hip*.so not built")]
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DT, GROWTH = np.float32(0.2), np.float32(0.1)
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _product(nb, cfg, bodies, steps, **kw):
+    st = nb.Stepper(cfg, **kw)
+    st.upload(bodies)
+    st.step(steps)
+    out = st.download()
+    st.close()
+    return out
+
+
+@pytest.mark.parametrize("n,field,radii,steps", [
+    (1024, 100000, "stock", 100),      # C1 (BASELINE configs[0]) over its whole horizon
+    (1000, 5000, "stock", 40),         # dense, ragged, frozen tail
+    (130, 3000, "stock", 12), (257, 3000, "stock", 12), (100, 3000, "stock", 12),   # index quirks
+    (65536, 100000, "r0", 25),         # C2 shape
+    (65536, 100000, "stock", 25),      # C3 shape: the count collapses 65536 -> 35k while it runs
+    (262144, 100000, "r0", 4),         # C4 / the metric's configuration
+    (262144, 100000, "stock", 3),
+])
+def test_product_equals_reference_kernels_bitwise(nb, n, field, radii, steps):
+    """Free-running from the reference's initial condition: the reference's kernels (no contraction) and the product end in
+    the same state, bit for bit - positions, velocities, masses, radii, survivor count."""
+    kw = {"minRadius": 0.0, "maxRadius": 0.0} if radii == "r0" else {}
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, **kw)
+    bodies = nb.init_bodies(cfg)
+    blk = bodies.contiguousData.copy()
+    n_ref, ms, _ = ol.ref_hip_run(blk, n, steps, DT, field, field, GROWTH)
+    out = _product(nb, cfg, bodies, steps)
+    assert out.numBodies == n_ref
+    assert np.array_equal(bits(out.block), bits(blk[:6 * n_ref])), "product != reference kernels after %d steps" % steps
+    print("\nN=%d %s: %d steps, %d -> %d bodies; reference kernels %.2f ms per step on this GPU" %
+          (n, radii, steps, n, n_ref, ms / steps))
+
+
+def test_reference_kernels_equal_cpu_oracle(nb):
+    """The same kernels against the CPU restatement (the oracle every other test uses), incl. pre-compaction state."""
+    for n, field in ((1000, 5000), (4096, 100000)):
+        cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field)
+        a = nb.init_bodies(cfg).contiguousData.copy()
+        b = a.copy()
+        na = nb_ = n
+        for s in range(6):
+            na, _, pre_a = ol.ref_hip_run(a, na, 1, DT, field, field, GROWTH, pre=True)
+            n_before = nb_
+            nb_, _, _, _, pre_b = ol.port_step(b, nb_, DT, field, field, GROWTH, want_events=False, pre=True)
+            assert na == nb_ and np.array_equal(bits(pre_a), bits(pre_b[:6 * n_before])), (n, s)
+            assert np.array_equal(bits(a[:6 * na]), bits(b[:6 * na]))
+
+
+@pytest.mark.ref
+def test_reference_kernels_equal_cpu_shim():
+    """The GPU run of the reference's kernel text against the CPU fiber shim that generated tests/golden/ (oracle/ref_shim):
+    the shim's stand-in execution model (fibers for threads, yields for __syncthreads) computes what the hardware computes."""
+    for n, field, steps in ((1000, 5000, 8), (200, 3000, 6), (2048, 100000, 4)):
+        a = ol.ref_init(n, field, field)
+        b = a.copy()
+        na = nb_ = n
+        for s in range(steps):
+            na, _, _ = ol.ref_hip_run(a, na, 1, DT, field, field, GROWTH)
+            nb_, _ = ol.ref_step(b, nb_, DT, field, field, GROWTH)
+            assert na == nb_ and np.array_equal(bits(a[:6 * na]), bits(b[:6 * na])), (n, s)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() /
+                 max(float(np.abs(np.asarray(b, np.float64)).max()), 1e-300))
+
+
+@pytest.mark.parametrize("n,radii", [(1024, "stock"), (65536, "stock"), (65536, "r0"), (262144, "r0"), (262144, "stock")])
+def test_product_within_tolerance_of_contracted_reference_kernels(nb, n, radii):
+    """The FMA reading ON THE GPU: the reference's kernels built with hipcc's default contraction.  Teacher-forced: from the
+    same state S_t (the contracted build's own trajectory, t = 0, 1, 2) one step of the product must give the same survivor
+    count, the same deleted bodies, bit-identical masses, and positions / velocities within 1e-5 norm-wise."""
+    kw = {"minRadius": 0.0, "maxRadius": 0.0} if radii == "r0" else {}
+    cfg = nb.stock_config(particleCount=n, **kw)
+    state = nb.init_bodies(cfg).contiguousData.copy()
+    cur = n
+    worst = 0.0
+    for t in range(3):
+        s_t = state[:6 * cur].copy()
+        n_next, _, pre = ol.ref_hip_run(state, cur, 1, DT, 100000, 100000, GROWTH, fma=True, pre=True)
+        fP, fV, fM, fR = ol.carve(pre, cur)
+        keep = fM != 0
+        st = nb.Stepper(cfg, capacity=cur)
+        st.upload(nb.BodiesData.from_block(s_t, cur))
+        st.step(1)
+        out = st.download()
+        st.close()
+        assert out.numBodies == n_next == int(keep.sum()), (t, out.numBodies, n_next)
+        assert np.array_equal(bits(out.Masses), bits(fM[keep])), "step %d: absorbed masses differ" % t
+        dp, dv, dr = _rel(out.Positions, fP[keep]), _rel(out.Velocities, fV[keep]), _rel(out.Radii, fR[keep])
+        assert dp <= 1e-5 and dv <= 1e-5 and dr <= 1e-6, (t, dp, dv, dr)
+        worst = max(worst, dp, dv)
+        cur = n_next
+    print("\nN=%d %s: product vs contracted reference kernels, worst rel difference over 3 teacher-forced steps: %.1e" %
+          (n, radii, worst))
