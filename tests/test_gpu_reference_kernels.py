@@ -39,10 +39,10 @@ def _product(nb, cfg, bodies, steps, **kw):
     (1024, 100000, "stock", 100),      # C1 (BASELINE configs[0]) over its whole horizon
     (1000, 5000, "stock", 40),         # dense, ragged, frozen tail
     (130, 3000, "stock", 12), (257, 3000, "stock", 12), (100, 3000, "stock", 12),   # index quirks
-    (65536, 100000, "r0", 25),         # C2 shape
-    (65536, 100000, "stock", 25),      # C3 shape: the count collapses 65536 -> 35k while it runs
-    (262144, 100000, "r0", 4),         # C4 / the metric's configuration
-    (262144, 100000, "stock", 3),
+    (65536, 100000, "r0", 1000),       # C2 (BASELINE configs[1]) over its whole 1000-step horizon
+    (65536, 100000, "stock", 1000),    # C3 (configs[2]) over its whole horizon: the count collapses 65536 -> ~7.8k
+    (262144, 100000, "r0", 25),        # C4 / the metric's configuration (its 1000 steps would take the reference 3.5 min)
+    (262144, 100000, "stock", 10),
 ])
 def test_product_equals_reference_kernels_bitwise(nb, n, field, radii, steps):
     """Free-running from the reference's initial condition: the reference's kernels (no contraction) and the product end in
