@@ -13,6 +13,10 @@ the 128-byte communicator id, the barriers and the max-over-ranks time.  After t
 checks ITSELF: the state the ranks hold (collective download) against a single-rank run of the same steps, bit for
 bit (`parity`), so a scaling line always carries its own correctness bit.
 
+Next to the CPU baseline (the oracle on the host cores, `cpu_baseline`) a 1-GPU fp32 run reports the speed of the
+reference's OWN kernels on the same GPU (`reference_kernels_on_this_gpu`: src/nbody.cu's device code compiled unmodified
+by hipcc, oracle/ref_hip) when that checker library has been built.
+
 Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region starts.
 """
 import argparse
@@ -323,7 +327,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
-            ref_gpu = reference_kernels_on_gpu(nb, bodies, cfg, out["ms_per_step"])
+            try:
+                ref_gpu = reference_kernels_on_gpu(nb, bodies, cfg, out["ms_per_step"])
+            except Exception as e:        # a baseline leg must never take the benchmark line down with it
+                ref_gpu = {"error": "%s: %s" % (type(e).__name__, e)}
             if ref_gpu is not None:
                 out["reference_kernels_on_this_gpu"] = ref_gpu
     if (world > 1 or a.force_comm) and not a.no_parity:
