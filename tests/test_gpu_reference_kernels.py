@@ -38,7 +38,9 @@ def _product(nb, cfg, bodies, steps, **kw):
 @pytest.mark.parametrize("n,field,radii,steps", [
     (1024, 100000, "stock", 100),      # C1 (BASELINE configs[0]) over its whole horizon
     (1000, 5000, "stock", 40),         # dense, ragged, frozen tail
-    (130, 3000, "stock", 12), (257, 3000, "stock", 12), (100, 3000, "stock", 12),   # index quirks
+    (1, 3000, "stock", 3), (2, 3000, "stock", 12), (100, 3000, "stock", 12), (127, 3000, "stock", 12),   # index quirks
+    (128, 3000, "stock", 12), (129, 3000, "stock", 12), (130, 3000, "stock", 12), (200, 3000, "stock", 12),   # 
+    (255, 3000, "stock", 12), (257, 3000, "stock", 12), (4096, 20000, "stock", 30),
     (65536, 100000, "r0", 1000),       # C2 (BASELINE configs[1]) over its whole 1000-step horizon
     (65536, 100000, "stock", 1000),    # C3 (configs[2]) over its whole horizon: the count collapses 65536 -> ~7.8k
     (262144, 100000, "r0", 25),        # C4 / the metric's configuration (its 1000 steps would take the reference 3.5 min)
