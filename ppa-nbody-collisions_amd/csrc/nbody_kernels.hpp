@@ -585,33 +585,35 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 #undef NB_V3_COUNT
 
 // ---------------------------------------------------------------------------------------------------------
-// Force + collision + drift kernel, variant "ring" (fp32): for own ranges with fewer chains than the chip has lanes.
+// Force + collision + drift kernel, variant "ring" (fp32): the fp32 force kernel at every size.
 //
-// A workgroup of kW waves serves 64 bodies; every wave holds the same 64 bodies (one per lane).  The walk is cut into
-// turns of kT positions and the turns go round the waves: wave w takes turns w, w + kW, w + 2 kW, ...  For its turn a
-// wave (1) has the tile entries its lanes need loaded straight from the replica into a private LDS window (direct-to-LDS
-// loads issued one own turn ahead), (2) evaluates the kT terms of every lane into registers - 12 of the 13 instructions
-// per pair, dependent on nothing -, (3) waits until the wave before it has published the running state of the chain
-// {fx, fy, deleted, mass/radius version} in LDS, (4) adds its kT terms to it in walk order (or, for a flagged lane / a
-// special tile, runs the general code on the kT positions), and (5) publishes the state for the next wave.  So the
-// ordered chain of every body passes through all waves in turn, each holding it only for kT adds, while the others
-// evaluate terms: no wave is a dedicated (half idle) chain wave, no term goes through LDS, there is no workgroup
-// barrier in the loop, and the instruction count per pair is that of the one-lane kernel plus the hand-off.
+// The per-body sum is a strictly ordered chain of N adds; only the terms are independent.  A RING of kW waves serves 64
+// bodies; every wave of the ring holds the same 64 bodies (one per lane).  The walk is cut into turns of kT positions and
+// the turns go round the waves: wave w takes turns w, w + kW, w + 2 kW, ...  For its turn a wave (1) has the tile
+// entries its lanes need loaded straight from the replica into a private LDS window (direct-to-LDS loads issued one own
+// turn ahead), (2) evaluates the kT terms of every lane into registers - 12 of the 13 instructions per pair, dependent
+// on nothing -, (3) polls until the wave before it has published the running sum, (4) adds its kT terms in walk order
+// (or, for a flagged lane / a special tile, runs the general code on the kT positions, from the same window), and (5)
+// publishes the state for the next wave.  No wave is a dedicated chain wave, no term goes through LDS, there is no
+// workgroup barrier in the loop.  A workgroup is kRings rings (1, 2 or 4: 64, 128 or 256 bodies) that fill a CU together.
 //
 // Hand-off = ONE 16-byte LDS record per lane {fx, fy, seq, flags}: written with one ds_write_b128, polled with one
 // ds_read_b128.  The LDS services a lane's whole 16 bytes in one array cycle for both instructions (MI355X_MICROARCH.md,
 // LDS table: lane groups), so a reader sees a record entirely old or entirely new (nbody_selftest_lds_record checks
 // exactly this); seq == tau means "the state after turn tau - 1".  Absorbed mass / radius change rarely: they travel
 // in a second record that is rewritten only when they change, with a per-lane version number in `flags`.
-// Round 1 lessons built in (profiles/r02_ring_*): the sequence number used to be accessed through a generic pointer
-// (flat_load / flat_store + s_waitcnt vmcnt(0): every poll waited for the window prefetch), and the direct-to-LDS loads
-// were compiler builtins, which make hipcc wait for them (vmcnt(0)) before ANY later LDS read: the prefetch was never in
-// flight during a turn.  Both are typed LDS accesses / inline assembly now and the only vmcnt wait is the one below.
+// Lessons built in (profiles/r02_ring_*): (a) a generic pointer to the sequence number compiles to flat_load / flat_store
+// + s_waitcnt vmcnt(0), and hipcc waits vmcnt(0) for the builtin form of the direct-to-LDS load before ANY later LDS
+// read: either way the window prefetch was never in flight.  Typed LDS accesses and inline assembly now; no
+// compiler-tracked vector-memory operation lives in the turn loop, hence no compiler-placed vmcnt wait in it.
+// (b) Rings that share a CU must be kept level, or the arbiter's older-wave-first rule lets one finish early and the CU
+// runs half empty: see the priority rule at the top of the loop.  (c) Every turn reads from the window: tile 0 is a
+// fast tile whose self position is masked, the truncated last tile is loaded whole across both window buffers.
+// (d) Meta::summary says whether ANY coordinate of the replica is unbounded / any radius non-zero: windows are scanned
+// only then.
 // A wait that exceeds p.spin_limit polls is reported (Counters::errors, sticky on the host) and POISONS the chain:
 // the state becomes NaN and a dead mark travels with the sequence number, so every later turn passes at once and
 // the step's output cannot be mistaken for a result.
-// First / last tile of a walk (self skip, truncation), the clean semantics' own tile and windows with unbounded
-// coordinates are done by the general code with records fetched from the replica.
 // ---------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* LdsPtr;
 typedef int Int4 __attribute__((ext_vector_type(4)));
