@@ -19,3 +19,9 @@ for shape in "262144 8 3 0 4 g8" "65536 1 0 0 8 n64k" "262144 1 0 0 2 g1"; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $O/${R:-r02}_pmc_ring_${6}_x3 -o runc --output-format csv -- python3 $P $1 $2 $3 $4 $5 > $O/${R:-r02}_pmc_ring_${6}_x3.log 2>&1
 done
 ls $O | grep ${R:-r02}_
+# (d) the fp64 production kernel at C5's size on one GPU and at C5's 8-rank shape
+for shape in "1048576 1 0 0 2 c5g1" "1048576 8 4 0 6 c5g8"; do
+  set -- $shape
+  rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_LDS --kernel-trace -d $O/${R:-r02}_pmc_f64_${6}_x1 -o runc --output-format csv -- python3 $P $1 $2 $3 $4 $5 r0 fp64 > $O/${R:-r02}_pmc_f64_${6}_x1.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_VALU_TRANS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace -d $O/${R:-r02}_pmc_f64_${6}_x2 -o runc --output-format csv -- python3 $P $1 $2 $3 $4 $5 r0 fp64 > $O/${R:-r02}_pmc_f64_${6}_x2.log 2>&1
+done
