@@ -7,6 +7,7 @@
  */
 #include "nbody.h"
 #include "nbody_error.h"
+#include "nbody_partition.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -179,4 +180,12 @@ void nbody_ctx_desc_from_config(nbody_ctx_desc* d, const nbody_config* cfg, int 
 
 int nbody_num_blocks(int numBodies) {
     return numBodies < 128 ? 1 : numBodies / 128;     /* src/nbody.cu:473 */
+}
+
+/* The partition rule as a C entry point (csrc/nbody_partition.h). */
+int nbody_partition(int n, int rank, int world, int* lo, int* cnt) {
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !cnt)
+        return nbody_fail(NBODY_ERR_INVALID, "nbody_partition: bad argument");
+    nbody_own_range_of(n, rank, world, lo, cnt);
+    return NBODY_OK;
 }

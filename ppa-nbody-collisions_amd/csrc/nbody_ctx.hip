@@ -183,10 +183,7 @@ int resolve_timing(nbody_ctx* c) {
 // output with NaNs); once seen it is sticky until the next nbody_upload.
 // Upper bound of any rank's own count when the body count is at most n: the partition is re-drawn every step, a
 // rank's range can grow by a block while the total shrinks, but never beyond ceil(blocks / world) blocks.
-int own_upper_of(const nbody_ctx* c, int n) {
-    const long long blocks = ((long long)n + kTile - 1) / kTile;
-    return (int)((blocks + c->desc.world - 1) / c->desc.world) * kTile;
-}
+int own_upper_of(const nbody_ctx* c, int n) { return nbody_own_upper_of(n, c->desc.world); }
 
 int device_failure(nbody_ctx* c, unsigned long long errors) {
     if (errors != 0) c->device_failed = true;
@@ -315,7 +312,7 @@ int launch_compute(nbody_ctx* c) {
         const int n_seen = *(volatile int*)&c->h_meta_async->n;
         if (n_seen > 0 && n_seen < c->n_upper) { c->n_upper = n_seen; c->own_upper = own_upper_of(c, n_seen); }
     }
-    // Workgroups cover every reference block of the own range, which starts on a block boundary (own_range_of).  The
+    // Workgroups cover every reference block of the own range, which starts on a block boundary (nbody_own_range_of).  The
     // body count only shrinks between syncs, so the host-side upper bound is safe; the kernel takes the exact range
     // from the device-side Meta and workgroups past it exit at once.
     const int nblocks = c->own_upper / kTile > 0 ? c->own_upper / kTile : 1;
@@ -402,13 +399,6 @@ int nbody_comm_unique_id(void* out128) {
     return NBODY_OK;
 }
 
-int nbody_partition(int n, int rank, int world, int* lo, int* cnt) {
-    if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !cnt)
-        return nbody_fail(NBODY_ERR_INVALID, "nbody_partition: bad argument");
-    own_range_of(n, rank, world, lo, cnt);
-    return NBODY_OK;
-}
-
 int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     if (!out || !d) return nbody_fail(NBODY_ERR_INVALID, "nbody_ctx_create: NULL argument");
     *out = nullptr;
@@ -442,10 +432,7 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     c->real_bytes = d->precision == NBODY_F64 ? 8 : 4;
     c->rec_bytes = 4 * c->real_bytes;
     c->cap = d->capacity;
-    {   // largest own range of the block-aligned partition (own_range_of): ceil(blocks / world) reference blocks
-        const long long blocks = ((long long)d->capacity + kTile - 1) / kTile;
-        c->cap_own = (int)((blocks + d->world - 1) / d->world) * kTile;
-    }
+    c->cap_own = nbody_own_upper_of(d->capacity, d->world);   // largest own range of the block-aligned partition
     c->ev_cap = d->event_capacity > 0 ? d->event_capacity : (1 << 20);
     c->slot_bytes = sizeof(SlotHeader) + (size_t)c->cap_own * (c->rec_bytes + 2 * c->real_bytes);   // records | velocities
     c->slot_bytes = (c->slot_bytes + 255) & ~(size_t)255;
@@ -520,7 +507,7 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     HIP_TRY(hipSetDevice(c->desc.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int lo = 0, cnt = 0;
-    own_range_of(n, c->desc.rank, c->desc.world, &lo, &cnt);
+    nbody_own_range_of(n, c->desc.rank, c->desc.world, &lo, &cnt);
     if (cnt > c->cap_own) return nbody_fail(NBODY_ERR_CAPACITY, "own range %d > own capacity %d", cnt, c->cap_own);
     // pack [P|V|M|R] (src/nbody.cu:66-77) into {x,y,m,r} records; Meta::summary as unpack_slots computes it per step
     int summary = 0;

@@ -20,6 +20,8 @@
 #include <stdint.h>
 #include <type_traits>
 
+#include "nbody_partition.h"
+
 #pragma clang fp contract(off)
 
 namespace nbk {
@@ -1116,19 +1118,6 @@ __global__ __launch_bounds__(kCompactBlock) void compact_scatter(const Rec<T>* _
     }
 }
 
-// The partition of N bodies over `world` ranks: whole reference blocks (128 bodies, src/nbody.cu:36), as evenly as
-// the block count allows, in rank order.  Block-aligned own ranges keep every ring / lane group of the force kernels
-// on bodies of one rank, and they are re-drawn from the survivor count after every step, so deletions never leave a
-// rank with more than its share (the reference compacts globally, :488-510).
-__host__ __device__ inline void own_range_of(int n, int rank, int world, int* lo, int* cnt) {
-    const long long blocks = ((long long)n + kTile - 1) / kTile;
-    long long first = blocks * rank / world * kTile, last = blocks * (rank + 1) / world * kTile;
-    if (first > n) first = n;
-    if (last > n) last = n;
-    *lo = (int)first;
-    *cnt = (int)(last - first);
-}
-
 // Builds step t+1 from the gathered slots of all ranks (global stable order = rank order): the replica of all
 // bodies, the velocities of THIS rank's new own range, and the new Meta.  A slot = header {count} | records[cap_own] |
 // velocities[cap_own].  grid = (ceil(cap_own / 256), world).
@@ -1144,7 +1133,7 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         total += c;
     }
     int lo, cnt;
-    own_range_of(total, rank, world, &lo, &cnt);
+    nbody_own_range_of(total, rank, world, &lo, &cnt);       // csrc/nbody_partition.h
     const unsigned char* slot = gather + (size_t)g * slot_bytes;
     const int c = reinterpret_cast<const SlotHeader*>(slot)->count;
     const Rec<T>* recs = reinterpret_cast<const Rec<T>*>(slot + sizeof(SlotHeader));

@@ -5,7 +5,8 @@
  *   driver blocks            exercise alloc / carve / init / compact / rng on several sizes
  *   driver peek <file>       nbody_state_peek on an arbitrary file
  *   driver state <file> <p>  save / peek / load round trip and refusals through a host-only stand-in context
- *   driver pgm <file>        nbody_write_pgm of a small image */
+ *   driver pgm <file>        nbody_write_pgm of a small image
+ *   driver partition         nbody_partition over many (n, world): covering, contiguous, block-aligned, level */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -135,6 +136,28 @@ int main(int argc, char** argv) {
         printf("rc=%d\n", nbody_write_pgm(argv[2], img, 7, 5));
         return 0;
     }
-    fprintf(stderr, "usage: driver parse|blocks|peek|pgm ...\n");
+    if (argc >= 2 && !strcmp(argv[1], "partition")) {
+        long checked = 0;
+        for (int n = 0; n <= 70000; n += (n < 600 ? 1 : 997))
+            for (int world = 1; world <= 9; ++world) {
+                int next = 0, lo = -1, cnt = -1, cmin = 1 << 30, cmax = 0;
+                for (int g = 0; g < world; ++g) {
+                    if (nbody_partition(n, g, world, &lo, &cnt) != NBODY_OK || lo != next || cnt < 0) return 1;
+                    if (cnt > 0 && lo % 128 != 0) return 1;
+                    next = lo + cnt;
+                    if (cnt < cmin) cmin = cnt;
+                    if (cnt > cmax) cmax = cnt;
+                    ++checked;
+                }
+                if (next != n || cmax - cmin > 255) return 1;
+            }
+        int lo, cnt;
+        if (nbody_partition(-1, 0, 1, &lo, &cnt) != NBODY_ERR_INVALID || nbody_partition(5, 2, 2, &lo, &cnt) != NBODY_ERR_INVALID ||
+            nbody_partition(5, 0, 1, NULL, &cnt) != NBODY_ERR_INVALID)
+            return 1;
+        printf("partition ok (%ld ranges)\n", checked);
+        return 0;
+    }
+    fprintf(stderr, "usage: driver parse|blocks|peek|pgm|partition ...\n");
     return 2;
 }

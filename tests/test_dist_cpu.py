@@ -7,7 +7,7 @@ The device code shards a step as: rank g owns a contiguous, block-aligned global
 (nbody_partition); it computes the post-step state of its range (reading the full replica), compacts its survivors
 into a fixed-size slot {count, records, velocities}, the slots are all-gathered, and every rank rebuilds the replica
 in rank order and RE-DRAWS the partition from the survivor count, taking the velocities of its new range from the
-slots (csrc/nbody_kernels.hpp: compact_scatter, unpack_slots, own_range_of; csrc/nbody_ctx.hip: nbody_step).  This
+slots (csrc/nbody_kernels.hpp: compact_scatter, unpack_slots; csrc/nbody_partition.h: nbody_own_range_of; csrc/nbody_ctx.hip: nbody_step).  This
 file runs that protocol over torch.distributed with the CPU oracle doing the per-range arithmetic (the oracle is the
 checker here, not a product path) and checks it against the single-rank oracle bit for bit - including deletions,
 ranges that move between ranks, and the index-dependent literal semantics, which depend on GLOBAL indices and the

@@ -187,6 +187,7 @@ def asan_driver(tmp_path_factory):
 
 def test_host_code_under_sanitizers(asan_driver, tmp_path):
     assert "blocks ok" in asan_driver("blocks")
+    assert "partition ok" in asan_driver("partition")
     for prec in (0, 1):
         assert asan_driver("state", str(tmp_path / "s.bin"), str(prec)).strip().endswith(
             "state same=1 small=-7 prec=-1 trunc=-3")
