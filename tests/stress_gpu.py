@@ -31,6 +31,7 @@ while time.time() - t0 < budget:
     variant = int(rng.choice(VARIANTS))
     world = int(rng.choice([1, 1, 2, 3, 5, 8]))
     steps = int(rng.integers(2, 7))
+    log = bool(rng.integers(0, 3) == 0)             # the event-logging builds of the kernels, events checked too
     cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=min_r, maxRadius=max_r,
                           maxRandBodyMass=max_m)
     bodies = nb.init_bodies(cfg)
@@ -39,18 +40,32 @@ while time.time() - t0 < budget:
         k = int(rng.integers(1, 6))
         src, dst = rng.integers(0, n, k), rng.integers(0, n, k)
         bodies.Positions[dst] = bodies.Positions[src]
-    grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant)
+    grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant, record_events=log)
     grp.upload(bodies)
     blk = bodies.contiguousData.copy()
     cur = n
     for s in range(steps):
         grp.step(1)
-        cur, *_ = ol.port_step(blk, cur, DT, field, field, GROWTH, semantics=sem, want_events=False)
+        n_before = cur
+        cur, ost, ab, de, _ = ol.port_step(blk, cur, DT, field, field, GROWTH, semantics=sem, want_events=log)
         out = grp.download()
-        if not (out.numBodies == cur and np.array_equal(out.block.view(np.uint32), blk[:6 * cur].view(np.uint32))):
+        ok_events = True
+        if log:
+            try:
+                ev = np.concatenate([r.events() for r in grp.ranks])
+            except nb.NbodyError:                    # more events than the log holds (very dense case): state check only
+                ev = None
+            if ev is not None and ost.n_absorb <= max(16, 4 * n_before):    # (the oracle's own event buffer holds 4n pairs)
+                ev = ev[ev["step"] == s]
+                got_abs = sorted((int(e["i"]), int(e["j"])) for e in ev[ev["kind"] == 0])
+                got_del = sorted(set(int(e["i"]) for e in ev[ev["kind"] == 1]))
+                ok_events = got_abs == sorted((int(a), int(b)) for a, b in ab) and got_del == sorted(int(d) for d in de)
+        if not (ok_events and out.numBodies == cur and
+                np.array_equal(out.block.view(np.uint32), blk[:6 * cur].view(np.uint32))):
             fails += 1
-            print("FAIL case %d step %d: n=%d field=%d r=[%g,%g] m=%g sem=%d variant=%d world=%d: got n=%d want %d" %
-                  (cases, s, n, field, min_r, max_r, max_m, sem, variant, world, out.numBodies, cur), flush=True)
+            print("FAIL case %d step %d: n=%d field=%d r=[%g,%g] m=%g sem=%d variant=%d world=%d log=%d events_ok=%d: got n=%d "
+                  "want %d" % (cases, s, n, field, min_r, max_r, max_m, sem, variant, world, log, ok_events, out.numBodies, cur),
+                  flush=True)
             break
         if cur == 0:
             break
