@@ -34,6 +34,17 @@ template <> struct alignas(16) Rec<float> { float x, y, m, r; };
 template <> struct alignas(32) Rec<double> { double x, y, m, r; };
 template <typename T> struct alignas(2 * sizeof(T)) Vec2 { T x, y; };
 
+// An fp64 record as it is kept in an LDS tile: 48 bytes apart instead of 32.  64 lanes reading consecutive 32-byte records
+// as two 16-byte halves are 2-way bank conflicted (a 16-lane group spans 512 bytes = two bank rows: 66 % of the LDS-array
+// cycles of the fp64 kernel were conflicts, profiles/r02_pmc_f64.txt); at a 48-byte stride the 16 lanes of a group fall
+// on 16 different 4-bank slots: conflict-free for both halves.
+struct alignas(16) RecPadded {
+    double x, y, m, r, pad0, pad1;
+    __device__ __forceinline__ RecPadded& operator=(const Rec<double>& o) { x = o.x; y = o.y; m = o.m; r = o.r; return *this; }
+    __device__ __forceinline__ operator Rec<double>() const { return Rec<double>{x, y, m, r}; }
+};
+static_assert(sizeof(RecPadded) == 48, "48-byte LDS stride");
+
 // Step-resident scalars, device memory.  Written by the unpack kernel, read by everything else.
 struct Meta {
     int n;        // global body count N_t
@@ -494,6 +505,7 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 // The same kernel in fp64 (256-thread form, one lane per body): the fp64 production kernel.  A record is 32 bytes,
 // 8 reads per batch (same-box A/B: 4 reads with the 4-waves register budget -0.4 %, 16 reads -4 %).
 #define NB_V3_ROTATE_PRIORITY
+#define NB_V3_TILE_REC RecPadded
 #define NB_V3_REAL double
 #define NB_V3_SIGNATURE                                                                                      \
     template <bool kLog>                                                                                     \
@@ -502,10 +514,10 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
         Rec<double>* __restrict__ S_J, Vec2<double>* __restrict__ S_V, const Meta* __restrict__ meta,        \
         StepParams<double> p, Event* ev, int ev_cap, Counters* ctr)
 #define NB_V3_LDS                                                                                            \
-    __shared__ Rec<T> tile_all[2][2][2 * kTile];                                                             \
+    __shared__ RecPadded tile_all[2][2][2 * kTile];                                                          \
     __shared__ int tile_bad_all[2][2][kTile / kWave];                                                        \
     __shared__ int tile_rnz_all[2][2][kTile / kWave];                                                        \
-    Rec<T>(&tile)[2][2 * kTile] = tile_all[threadIdx.x / kTile];                                             \
+    RecPadded(&tile)[2][2 * kTile] = tile_all[threadIdx.x / kTile];                                          \
     int(&tile_bad)[2][kTile / kWave] = tile_bad_all[threadIdx.x / kTile];                                    \
     int(&tile_rnz)[2][kTile / kWave] = tile_rnz_all[threadIdx.x / kTile];
 #define NB_V3_LANE const int lane = threadIdx.x % kTile;
@@ -522,6 +534,7 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
     if ((lane & (kWave - 1)) == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
 #include "nbody_forces_v3.inc"
 #undef NB_V3_ROTATE_PRIORITY
+#undef NB_V3_TILE_REC
 #undef NB_V3_REAL
 #undef NB_V3_SIGNATURE
 #undef NB_V3_LDS
