@@ -344,6 +344,32 @@ __device__ __forceinline__ Pair<float>::type fast_inv_cube2(Pair<float>::type d2
     const V e2 = __builtin_elementwise_fma(-c, r, one);
     return __builtin_elementwise_fma(e2, r, r);
 }
+// Two packed chains written side by side: a packed instruction is then followed by an independent one and not by its
+// dependent, which would need a wait state (hipcc keeps the order it is given here).
+__device__ __forceinline__ void fast_inv_cube2x2(Pair<float>::type d2a, Pair<float>::type d2b, Pair<float>::type& inva,
+                                                 Pair<float>::type& invb) {
+    typedef Pair<float>::type V;
+    V ya, yb;
+    ya.x = __builtin_amdgcn_rsqf(d2a.x);
+    ya.y = __builtin_amdgcn_rsqf(d2a.y);
+    yb.x = __builtin_amdgcn_rsqf(d2b.x);
+    yb.y = __builtin_amdgcn_rsqf(d2b.y);
+    const V ga = d2a * ya, gb = d2b * yb;
+    const V ha = ya * 0.5f, hb = yb * 0.5f;
+    const V ea = __builtin_elementwise_fma(-ga, ga, d2a), eb = __builtin_elementwise_fma(-gb, gb, d2b);
+    const V da = __builtin_elementwise_fma(ea, ha, ga), db = __builtin_elementwise_fma(eb, hb, gb);
+    const V sa = da * da, sb = db * db;
+    const V ca = sa * da, cb = sb * db;
+    V ra, rb;
+    ra.x = __builtin_amdgcn_rcpf(ca.x);
+    ra.y = __builtin_amdgcn_rcpf(ca.y);
+    rb.x = __builtin_amdgcn_rcpf(cb.x);
+    rb.y = __builtin_amdgcn_rcpf(cb.y);
+    const V one = {1.0f, 1.0f};
+    const V fa = __builtin_elementwise_fma(-ca, ra, one), fb = __builtin_elementwise_fma(-cb, rb, one);
+    inva = __builtin_elementwise_fma(fa, ra, ra);
+    invb = __builtin_elementwise_fma(fb, rb, rb);
+}
 __device__ __forceinline__ Pair<double>::type fast_inv_cube2(Pair<double>::type d2) {
     Pair<double>::type inv;                                // no packed fp64 instructions: two scalar chains
     inv.x = fast_chain(d2.x).inv;
@@ -606,8 +632,10 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 // bodies; every wave of the ring holds the same 64 bodies (one per lane).  The walk is cut into turns of kT positions and
 // the turns go round the waves: wave w takes turns w, w + kW, w + 2 kW, ...  For its turn a wave (1) has the tile
 // entries its lanes need loaded straight from the replica into a private LDS window (direct-to-LDS loads issued one own
-// turn ahead), (2) evaluates the kT terms of every lane into registers - 12 of the 13 instructions per pair, dependent
-// on nothing -, (3) polls until the wave before it has published the running sum, (4) adds its kT terms in walk order
+// turn ahead; the window is component-major, so that two consecutive walk positions of a lane are one ds_read2_b32
+// into the register pair of a packed instruction), (2) evaluates the kT terms of every lane into registers - all but
+// the two adds per pair, dependent on nothing, two walk positions per packed instruction throughout -, (3) polls
+// until the wave before it has published the running sum, (4) adds its kT terms in walk order
 // (or, for a flagged lane / a special tile, runs the general code on the kT positions, from the same window), and (5)
 // publishes the state for the next wave.  No wave is a dedicated chain wave, no term goes through LDS, there is no
 // workgroup barrier in the loop.  A workgroup is kRings rings (1, 2 or 4: 64, 128 or 256 bodies) that fill a CU together.
@@ -638,11 +666,13 @@ typedef volatile __attribute__((address_space(3))) Float2* LdsFloat2Ptr;
 
 constexpr int kRingDeadSeq = 0x40000000;                   // sequence number of a poisoned chain
 
-// 16 bytes per active lane from global memory straight into LDS at lds_base + 16 * lane (gfx950 LDS-DMA).  Inline
-// assembly on purpose: hipcc tracks the builtin form as a writer of all LDS and waits vmcnt(0) before the next LDS read.
-// M0 is written by nothing else in these kernels (gfx9 DS instructions do not use it).
-__device__ __forceinline__ void load_to_lds_b128(const void* base, unsigned byte_offset, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+// Global memory straight into LDS (gfx950 LDS-DMA).  Inline assembly on purpose: hipcc tracks the builtin form as a writer
+// of all LDS and waits vmcnt(0) before the next LDS read.  M0 is written by nothing else in these kernels (gfx9 DS
+// instructions do not use it).
+// 4 bytes per active lane: lane l's dword lands at lds_base + 4 * l.  The SOURCE address is per lane, so a strided gather
+// from the {x, y, m, r} records turns one component of 64 bodies into 64 consecutive LDS words.
+__device__ __forceinline__ void load_to_lds_b32(const void* base, unsigned byte_offset, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
                  ::"s"(lds_base), "v"(byte_offset), "s"(base) : "memory");
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
@@ -660,7 +690,11 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     constexpr int kTilesPerRound = kW / kTurnsPerTile;
     constexpr int kWin = kWave + kT;                       // window entries a turn can touch (kWin - 1 used)
     static_assert(kRings == 1 || kRings == 2 || kRings == 4, "rings (64 bodies each) per workgroup");
-    __shared__ Rec<T> win_all[kRings][kW][2][kWin];        // per wave, double buffered
+    // Per wave, double buffered, COMPONENT-MAJOR: x[kWin] y[kWin] m[kWin] r[kWin].  A lane's walk positions r, r + 1 are
+    // then two consecutive words of each component: one ds_read2_b32 fills the register pair a packed fp32 instruction
+    // takes, so two walk positions share EVERY instruction of the term (with records in LDS the differences and squares
+    // were packed per position: one more instruction per pair, plus moves that paired the mass with its operand).
+    __shared__ float win_all[kRings][kW][2][4][kWin];
     __shared__ Int4 hand_all[kRings][kWave];               // {fx, fy, seq, flags = version << 1 | deleted} per lane
     __shared__ Float2 hand_m_all[kRings][kWave];           // {mnew, rnew}, rewritten only when they change
     const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
@@ -677,7 +711,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     const int t0 = half * kWave;
     const int t = t0 + l;                                  // threadIdx.x of this lane's body in the reference
     const long long blk0 = (long long)b * kTile;
-    Rec<T>(&win)[kW][2][kWin] = win_all[ring];
+    float(&win)[kW][2][4][kWin] = win_all[ring];
     Int4(&hand)[kWave] = hand_all[ring];
     Float2(&hand_m)[kWave] = hand_m_all[ring];
     const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
@@ -762,21 +796,37 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const unsigned wrapped = src - (unsigned)N;        // huge when src < N
         return (src < wrapped ? src : wrapped) * (unsigned)sizeof(Rec<T>);
     };
-    // Loaded from the replica STRAIGHT INTO LDS (lane l's 16 bytes land at base + 16 l): the prefetch holds no
-    // registers and stays in flight for a whole turn.
-    auto issue_window = [&](long long st, int buf) {
-        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0]));
-        if (l < nwin) load_to_lds_b128(J, window_offset(st, e0), base);
-        if (l + kWave < nwin) load_to_lds_b128(J, window_offset(st, e1), base + kWave * (unsigned)sizeof(Rec<T>));
+    // Loaded from the replica STRAIGHT INTO LDS, one component of 64 bodies per instruction (lane l's word lands at
+    // base + 4 l; the per-lane source address does the transposition): the prefetch holds no registers and stays in
+    // flight for a whole turn.  The radii are only fetched when some radius of the replica is not +0 (Meta::summary).
+    const char* const Jx = (const char*)J;
+    const char* const Jy = Jx + sizeof(T);
+    const char* const Jm = Jx + 2 * sizeof(T);
+    const char* const Jr = Jx + 3 * sizeof(T);
+    auto issue_entries = [&](unsigned byte_offset, unsigned base, unsigned comp_bytes) {
+        load_to_lds_b32(Jx, byte_offset, base);
+        load_to_lds_b32(Jy, byte_offset, base + comp_bytes);
+        load_to_lds_b32(Jm, byte_offset, base + 2 * comp_bytes);
+        if (any_radius) load_to_lds_b32(Jr, byte_offset, base + 3 * comp_bytes);
     };
-    // A truncated tile: its L <= 128 entries in order, across BOTH window buffers (2 * kWin >= 128 records), so it
-    // can only be issued when the wave is done with its current window: after the hand-off of the turn before.
+    auto issue_window = [&](long long st, int buf) {
+        const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0][0]));
+        if (l < nwin) issue_entries(window_offset(st, e0), base, kWin * (unsigned)sizeof(T));
+        if (l + kWave < nwin) issue_entries(window_offset(st, e1), base + kWave * (unsigned)sizeof(T), kWin * (unsigned)sizeof(T));
+    };
+    // A truncated tile: its L <= 128 entries in order, component-major x[128] y[128] m[128] r[128] across BOTH window
+    // buffers (2 * 4 * kWin >= 4 * 128 words), so it can only be issued when the wave is done with its current window:
+    // after the hand-off of the turn before.
     static_assert(2 * kWin >= kTile, "a whole tile fits the two window buffers");
-    Rec<T>* const whole = &win[w][0][0];
+    float* const whole = &win[w][0][0][0];
     auto issue_truncated = [&](long long st, int L) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(whole));
-        if (l < L) load_to_lds_b128(J, window_offset(st, (unsigned)l), base);
-        if (l + kWave < L) load_to_lds_b128(J, window_offset(st, (unsigned)(l + kWave)), base + kWave * (unsigned)sizeof(Rec<T>));
+        if (l < L) issue_entries(window_offset(st, (unsigned)l), base, kTile * (unsigned)sizeof(T));
+        if (l + kWave < L) issue_entries(window_offset(st, (unsigned)(l + kWave)), base + kWave * (unsigned)sizeof(T), kTile * (unsigned)sizeof(T));
+    };
+    // one entry of a window / of the whole truncated tile, as a record (general code only)
+    auto window_record = [&](const float* comp0, int stride, int idx) -> Rec<T> {
+        return Rec<T>{comp0[idx], comp0[stride + idx], comp0[2 * stride + idx], any_radius ? comp0[3 * stride + idx] : 0.0f};
     };
     // after the loads have landed: are all coordinates of the window bounded, is some radius not +0.0f
     struct WindowState { bool fast, rnz; };
@@ -787,8 +837,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         // the whole replica is bounded (Meta::summary): no scan of the window; all its radii are +0 or not, globally
         if (all_bounded) return WindowState{wave_ok && fast_tile(kk), any_radius};
         Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
-        if (l < nwin) r0 = win[w][buf][l];
-        if (l + kWave < nwin) r1 = win[w][buf][l + kWave];
+        if (l < nwin) r0 = window_record(&win[w][buf][0][0], kWin, l);
+        if (l + kWave < nwin) r1 = window_record(&win[w][buf][0][0], kWin, l + kWave);
         const bool bad0 = !((abs_(r0.x) < kCoordBound) && (abs_(r0.y) < kCoordBound));
         const bool bad1 = !((abs_(r1.x) < kCoordBound) && (abs_(r1.y) < kCoordBound));
         WindowState ws;
@@ -818,7 +868,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 j = st + off;
                 if (j == i64) continue;
             }
-            const Rec<T> rec = kind == 1 ? win[w][buf][(lit ? l : 0) + (off - off0)] : whole[sidx];
+            const Rec<T> rec = kind == 1 ? window_record(&win[w][buf][0][0], kWin, (lit ? l : 0) + (off - off0))
+                                         : window_record(whole, kTile, sidx);
             interact<T, kLog>(a, rec, p.growth, i, (int)j, ev, ev_cap, ctr, step);
         }
     };
@@ -862,55 +913,56 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             if (*seq_mine < ahead) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
-        // (2) the kT terms of this turn
-        V2 term[kT];
+        // (2) the kT terms of this turn: walk positions 2v, 2v + 1 in the two halves of termx[v] / termy[v]
+        V2 termx[kT / 2], termy[kT / 2];
         unsigned long long flag = 0;
         if (fast) {
-            const Rec<T>* walk = &win[w][buf][lit ? l : 0];
-            V2 own;
-            own.x = a.xi; own.y = a.yi;
+            const float* wx = &win[w][buf][0][lit ? l : 0];
+            const float* wy = wx + kWin;
+            const float* wm = wx + 2 * kWin;
+            int r_at = 3 * kWin;                           // beyond the reach of wx's immediate offsets: its own base
+            asm("" : "+v"(r_at));                          // register (hipcc otherwise recomputes the address per read)
+            const float* wr = wx + r_at;
+            const V2 ownx = {a.xi, a.xi}, owny = {a.yi, a.yi};
             float closest = kFastHi;                       // zero-radius path: the smallest d2 of the turn, per lane
             auto evaluate = [&](auto r0_tag) {
                 constexpr bool kR0 = decltype(r0_tag)::value;
-                constexpr int kG = (kR0 && kT <= 16) ? 8 : 4;   // reads per batch: the terms already take 2 kT VGPRs
 #pragma unroll
-                for (int r0 = 0; r0 < kT; r0 += kG) {
-                    Rec<T> rec[kG];
-#pragma unroll
-                    for (int u = 0; u < kG; ++u) rec[u] = walk[r0 + u];
+                for (int r0 = 0; r0 < kT; r0 += 4) {       // four walk positions per batch of reads: a, a, b, b
+                    const V2 xa = {wx[r0], wx[r0 + 1]}, xb = {wx[r0 + 2], wx[r0 + 3]};
+                    const V2 ya = {wy[r0], wy[r0 + 1]}, yb = {wy[r0 + 2], wy[r0 + 3]};
+                    const V2 ma = {wm[r0], wm[r0 + 1]}, mb = {wm[r0 + 2], wm[r0 + 3]};
+                    V2 ra = {0.0f, 0.0f}, rb = {0.0f, 0.0f};
+                    if (!kR0) { ra = V2{wr[r0], wr[r0 + 1]}; rb = V2{wr[r0 + 2], wr[r0 + 3]}; }
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < kG; u += 2) {
-                        const Rec<T> ba = rec[u], bb = rec[u + 1];
-                        V2 pa, pb;
-                        pa.x = ba.x; pa.y = ba.y;
-                        pb.x = bb.x; pb.y = bb.y;
-                        const V2 da = pa - own, db = pb - own;
-                        const V2 sa = da * da, sb = db * db;
-                        V2 d2, q;
-                        d2.x = add_unmerged(sa.x, sa.y);
-                        d2.y = add_unmerged(sb.x, sb.y);
-                        q.x = kFastLo; q.y = kFastLo;
-                        if (!kR0) {
-                            V2 rs;
-                            rs.x = a.ri + ba.r; rs.y = a.ri + bb.r;
-                            q = __builtin_elementwise_fma(rs, rs, q);          // flag only
-                        }
-                        if (kR0) {
-                            // all radii +0: the threshold is 2^-80 for every pair, so ONE comparison of the turn's
-                            // smallest d2 decides (half an instruction per pair; d2 is finite here - the coordinates
-                            // are bounded - so no NaN can hide in the minimum)
-                            const float da2 = (r0 + u == 0 && first) ? kFastHi : d2.x;
-                            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(da2), "v"(d2.y));
-                        } else {
-                            const unsigned long long close_a = le_mask(d2.x, q.x);
-                            flag |= (r0 + u == 0 && first) ? 0ull : close_a;
-                            flag |= le_mask(d2.y, q.y);
-                        }
-                        const V2 inv = fast_inv_cube2(d2);
-                        term[r0 + u] = (da * ba.m) * inv.x;
-                        term[r0 + u + 1] = (db * bb.m) * inv.y;
+                    const V2 dxa = xa - ownx, dxb = xb - ownx;
+                    const V2 dya = ya - owny, dyb = yb - owny;
+                    const V2 sxa = dxa * dxa, sxb = dxb * dxb;
+                    const V2 sya = dya * dya, syb = dyb * dyb;
+                    const V2 d2a = sxa + sya, d2b = sxb + syb;   // three roundings per element (no contraction in this file)
+                    if (kR0) {
+                        // all radii +0: the threshold is 2^-80 for every pair, so ONE comparison of the turn's
+                        // smallest d2 decides (half an instruction per pair; d2 is finite here - the coordinates
+                        // are bounded - so no NaN can hide in the minimum)
+                        const float first_d2 = (r0 == 0 && first) ? kFastHi : d2a.x;
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(first_d2), "v"(d2a.y));
+                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2b.x), "v"(d2b.y));
+                    } else {
+                        const V2 ri2 = {a.ri, a.ri}, lo2 = {kFastLo, kFastLo};
+                        const V2 rsa = ri2 + ra, rsb = ri2 + rb;
+                        const V2 qa = __builtin_elementwise_fma(rsa, rsa, lo2), qb = __builtin_elementwise_fma(rsb, rsb, lo2);
+                        const unsigned long long close_a = le_mask(d2a.x, qa.x);   // flag only
+                        flag |= (r0 == 0 && first) ? 0ull : close_a;
+                        flag |= le_mask(d2a.y, qa.y);
+                        flag |= le_mask(d2b.x, qb.x);
+                        flag |= le_mask(d2b.y, qb.y);
                     }
+                    V2 inva, invb;
+                    fast_inv_cube2x2(d2a, d2b, inva, invb);
+                    const V2 txa = dxa * ma, txb = dxb * mb;
+                    const V2 tya = dya * ma, tyb = dyb * mb;
+                    termx[r0 / 2] = txa * inva; termx[r0 / 2 + 1] = txb * invb;
+                    termy[r0 / 2] = tya * inva; termy[r0 / 2 + 1] = tyb * invb;
                 }
                 if (kR0) flag = le_mask(closest, kFastLo);
             };
@@ -918,7 +970,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             else evaluate(std::false_type{});
             // the reference skips the self position; the sum starts at +0.0f and +0 + +0 = +0: adding a zero term is
             // the same bits (whatever the self "pair" evaluated to is dropped here)
-            if (first) term[0] = V2{0.0f, 0.0f};
+            if (first) { termx[0].x = 0.0f; termy[0].x = 0.0f; }
         }
         if (kProbe) pt1 = __builtin_readcyclecounter();
         // (3) the state after turn tau - 1.  Polled at raised priority: a poll is one LDS read plus scalar work, it
@@ -948,9 +1000,9 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             float fx = __int_as_float(h.x), fy = __int_as_float(h.y);
 #pragma unroll
             for (int r = 0; r < kT; ++r) {
-                fx = fx + term[r].x;
+                fx = fx + ((r & 1) ? termx[r / 2].y : termx[r / 2].x);
                 asm("" : "+v"(fx));                        // keeps hipcc from pairing the two adds into one v_pk_add_f32
-                fy = fy + term[r].y;
+                fy = fy + ((r & 1) ? termy[r / 2].y : termy[r / 2].x);
             }
             if (tau + 1 < nturns)
                 *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, flags_in};
@@ -972,8 +1024,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                         float fx = a.fx, fy = a.fy;
 #pragma unroll
                         for (int r = 0; r < kT; ++r) {
-                            fx = add_unmerged(fx, term[r].x);
-                            fy = add_unmerged(fy, term[r].y);
+                            fx = add_unmerged(fx, (r & 1) ? termx[r / 2].y : termx[r / 2].x);
+                            fy = add_unmerged(fy, (r & 1) ? termy[r / 2].y : termy[r / 2].x);
                         }
                         a.fx = fx; a.fy = fy;
                     }

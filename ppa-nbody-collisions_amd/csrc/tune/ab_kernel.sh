@@ -1,9 +1,9 @@
-# Same-box A/B of two builds of the library (build/libnbody_A.so, build/libnbody_B.so: build/ is git-ignored but travels with
+# Same-box A/B of builds of the library (build/libnbody_A.so, build/libnbody_B.so, ...; VARIANTS="A B C": build/ is git-ignored but travels with
 # gpurun): one rank's force kernel in steady state (rank_kernel.py) at the 1-rank, 8-rank and N=65536 shapes, two rounds.
 P=ppa-nbody-collisions_amd
 cp $P/libnbody_mi355x.so /tmp/orig.so
 for round in 1 2; do
-  for v in A B; do
+  for v in ${VARIANTS:-A B}; do
     cp build/libnbody_$v.so $P/libnbody_mi355x.so
     for shape in "262144 1 0 0 6" "262144 8 4 0 40" "65536 1 0 0 60" "65536 1 0 0 60 stock"; do
       echo -n "$v r$round: "; python3 $P/csrc/tune/rank_kernel.py $shape 2>&1 | grep -v amdgpu | cut -c1-120
