@@ -28,6 +28,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's multi-process set-up fails with
+# `hipIpcGetMemHandle: invalid argument` (must be in the environment before anything initialises HIP)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FLOP_PER_PAIR = 20.0            # SURVEY.md 8d convention (18 + sqrt + divide)
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (packed issue)
@@ -334,8 +337,12 @@ def main():
             if ref_gpu is not None:
                 out["reference_kernels_on_this_gpu"] = ref_gpu
     if (world > 1 or a.force_comm) and not a.no_parity:
-        # every rank takes part (the download is a collective); rank 0 compares and reports
-        par = parity_of_ranks(nb, st, bodies, cfg, precision, local_rank, a.warmup + a.steps, rank)
+        # every rank takes part (the download is a collective); rank 0 compares and reports.  A failing check must
+        # not take the measured line down with it: it is reported in the line instead.
+        try:
+            par = parity_of_ranks(nb, st, bodies, cfg, precision, local_rank, a.warmup + a.steps, rank)
+        except Exception as e:
+            par = {"error": "%s: %s" % (type(e).__name__, e), "bitwise_equal": False}
         if rank == 0:
             out["parity" if world > 1 else "parity_rccl_path"] = par
             out["config"]["rccl_ranks"] = world

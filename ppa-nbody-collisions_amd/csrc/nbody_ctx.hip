@@ -266,11 +266,11 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 18: launch_v3<8>(c, p, nblocks, log); return;
         case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
         case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
-        case 50: launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log); return;   // 2 rings of 8 waves per workgroup
-        case 52: launch_ring<4, 32, 2, false, 4>(c, p, nblocks, log); return;   // 4 rings of 4 waves per workgroup
+        case 50: launch_ring<8, 32, 8, false, 2>(c, p, nblocks, log); return;   // 2 rings of 8 waves per workgroup
+        case 52: launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log); return;   // 4 rings of 4 waves per workgroup
         case 54: launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log); return;   // one ring of 8 waves per workgroup
-        case 53: launch_ring<8, 16, 2, false, 2>(c, p, nblocks, log); return;   // tuning: turns of 16 positions
-        case 58: launch_ring<8, 32, 2, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
+        case 53: launch_ring<8, 16, 8, false, 2>(c, p, nblocks, log); return;   // tuning: turns of 16 positions
+        case 58: launch_ring<8, 32, 8, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many ordered chains there are to fill the chip with
@@ -281,8 +281,11 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     //                   (4.35 ms at 32768 own bodies of 262144; 4 x 4: 5.4)
     //   below         : ring kernel, one ring of 8 waves per workgroup: twice the workgroups to spread over the CUs
     //                   (0.21 ms at N = 16384; 2 x 8: 0.29; the producer/consumer kernel of round 1: 0.31)
-    if (c->own_upper >= 49152) launch_ring<4, 32, 2, false, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 24576) launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log);
+    // Poll interval of the hand-off wait: s_sleep 8 (512 cycles) where the launch is bound by evaluation - a poll takes
+    // issue slots from the waves that evaluate: -0.5 ... -1 % against s_sleep 2 -, s_sleep 2 for the small launches, which
+    // are bound by the chain (N = 16384: 0.185 ms; with s_sleep 8: 0.218).
+    if (c->own_upper >= 49152) launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log);
+    else if (c->own_upper >= 24576) launch_ring<8, 32, 8, false, 2>(c, p, nblocks, log);
     else launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log);
 }
 
