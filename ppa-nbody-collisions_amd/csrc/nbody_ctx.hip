@@ -105,6 +105,8 @@ struct nbody_ctx {
     unsigned char* gather = nullptr;  // world * slot_bytes                    (== slot when world == 1)
     size_t slot_bytes = 0;
     int* blk_counts = nullptr;
+    unsigned* tile_rmax = nullptr;  // per aligned 128-body tile of J: bits of max |radius| (NaN skipped); see unpack_slots
+    int n_tiles = 0;                // cap / 128 + 2
     Meta* meta = nullptr;
     Meta* meta_all = nullptr;       // RCCL contexts: every rank's Meta, all-gathered by nbody_download
     Counters* counters = nullptr;
@@ -250,8 +252,8 @@ void launch_v3w(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log)
 template <int kW, int kT, int kSleep, bool kProbe, int kRings>
 void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = (nblocks * 2 + kRings - 1) / kRings;  // a workgroup serves kRings rings of 64 bodies, two per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float));
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax);
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax);
 }
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
@@ -324,7 +326,7 @@ int launch_compute(nbody_ctx* c) {
     const int nblk = (c->own_upper + kCompactBlock - 1) / kCompactBlock > 0
                          ? (c->own_upper + kCompactBlock - 1) / kCompactBlock : 1;
     hipLaunchKernelGGL((compact_count<T>), dim3(nblk), dim3(kCompactBlock), 0, c->stream,
-                       (const Rec<T>*)c->S_J, (const Meta*)c->meta, c->blk_counts);
+                       (const Rec<T>*)c->S_J, (const Meta*)c->meta, c->blk_counts, c->tile_rmax, c->n_tiles);
     hipLaunchKernelGGL((compact_scatter<T>), dim3(nblk), dim3(kCompactBlock), 0, c->stream,
                        (const Rec<T>*)c->S_J, (const Vec2<T>*)c->S_V, (const Meta*)c->meta,
                        (const int*)c->blk_counts, nblk, (SlotHeader*)c->slot,
@@ -342,7 +344,7 @@ int launch_commit(nbody_ctx* c) {
     const int gx_all = c->desc.world > 1 ? (c->cap_own + 255) / 256 : gx;
     hipLaunchKernelGGL((unpack_slots<T>), dim3(gx_all, c->desc.world), dim3(256), 0, c->stream,
                        (const unsigned char*)c->gather, c->slot_bytes, c->cap_own, c->desc.world, c->desc.rank,
-                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta);
+                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta, c->tile_rmax);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
@@ -377,7 +379,7 @@ void free_all(nbody_ctx* c) {
     hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
     if (c->gather && c->gather != c->slot) hipFree(c->gather);
     hipFree(c->slot);
-    hipFree(c->blk_counts); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
+    hipFree(c->blk_counts); hipFree(c->tile_rmax); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_meta) hipHostFree(c->h_meta);
     if (c->h_meta_async) hipHostFree(c->h_meta_async);
@@ -461,6 +463,9 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     if (d->world > 1 || use_comm) CTX_TRY(hipMalloc((void**)&c->gather, c->slot_bytes * d->world));
     else c->gather = c->slot;
     CTX_TRY(hipMalloc((void**)&c->blk_counts, sizeof(int) * (size_t)(c->cap_own / kCompactBlock + 2)));
+    c->n_tiles = c->cap / kTile + 2;
+    CTX_TRY(hipMalloc((void**)&c->tile_rmax, sizeof(unsigned) * (size_t)c->n_tiles));
+    CTX_TRY(hipMemset(c->tile_rmax, 0, sizeof(unsigned) * (size_t)c->n_tiles));
     CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
     if (use_comm) CTX_TRY(hipMalloc((void**)&c->meta_all, sizeof(Meta) * (size_t)d->world));
     CTX_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
@@ -540,6 +545,18 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
         }
         HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<float>), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    {   // per-tile radius bounds, as unpack_slots maintains them from then on
+        std::vector<unsigned> tr((size_t)c->n_tiles, 0u);
+        for (int i = 0; i < n; ++i) {
+            const float ar = c->desc.precision == NBODY_F64 ? (float)fabs(((const double*)block)[5 * (size_t)n + i])
+                                                            : fabsf(((const float*)block)[5 * (size_t)n + i]);
+            unsigned bits;
+            memcpy(&bits, &ar, 4);
+            if (ar == ar && bits > tr[i / kTile]) tr[i / kTile] = bits;
+        }
+        HIP_TRY(hipMemcpyAsync(c->tile_rmax, tr.data(), sizeof(unsigned) * tr.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // tr goes out of scope
     }
     c->h_meta->n = n; c->h_meta->lo = lo; c->h_meta->cnt = cnt; c->h_meta->step = 0; c->h_meta->n_prev = n;
     c->h_meta->summary = summary; c->h_meta->pad[0] = c->h_meta->pad[1] = 0;

@@ -671,9 +671,13 @@ constexpr int kRingDeadSeq = 0x40000000;                   // sequence number of
 // instructions do not use it).
 // 4 bytes per active lane: lane l's dword lands at lds_base + 4 * l.  The SOURCE address is per lane, so a strided gather
 // from the {x, y, m, r} records turns one component of 64 bodies into 64 consecutive LDS words.
-__device__ __forceinline__ void load_to_lds_b32(const void* base, unsigned byte_offset, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                 ::"s"(lds_base), "v"(byte_offset), "s"(base) : "memory");
+// The instruction's immediate offset is added to the global address AND to the LDS address: component c of the records
+// (kImm = 4 c) therefore needs M0 = (where the component array starts) - kImm, and all four components share ONE base
+// pointer (scalar registers are scarce in the ring kernel: every pair spilled to a VGPR lane costs v_readlanes per turn).
+template <int kImm>
+__device__ __forceinline__ void load_to_lds_b32(const void* base, unsigned byte_offset, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%3"
+                 ::"s"(lds_dst - (unsigned)kImm), "v"(byte_offset), "s"(base), "n"(kImm) : "memory");
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
 
@@ -681,7 +685,7 @@ template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings>
 __global__ __launch_bounds__(kRings * kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
                      Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
-                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr) {
+                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr, const float* __restrict__ tile_rmax) {
     typedef float T;
     typedef Pair<float>::type V2;
     static_assert(kTile % kT == 0 && kT % 8 == 0 && kT <= kWave, "turn length");
@@ -737,7 +741,6 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     int timeouts = 0;
     const bool lane_ok = !active || ((abs_(a.xi) < kCoordBound) && (abs_(a.yi) < kCoordBound));
     const bool wave_ok = __ballot(!lane_ok) == 0ull;
-    const bool wave_r0 = __ballot(active && not_plus_zero(a.ri)) == 0ull;
     unsigned long long pairs = 0;
     const LdsInt4Ptr hand_l = (LdsInt4Ptr)&hand[l];
     const LdsFloat2Ptr hand_m_l = (LdsFloat2Ptr)&hand_m[l];
@@ -799,15 +802,11 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     // Loaded from the replica STRAIGHT INTO LDS, one component of 64 bodies per instruction (lane l's word lands at
     // base + 4 l; the per-lane source address does the transposition): the prefetch holds no registers and stays in
     // flight for a whole turn.  The radii are only fetched when some radius of the replica is not +0 (Meta::summary).
-    const char* const Jx = (const char*)J;
-    const char* const Jy = Jx + sizeof(T);
-    const char* const Jm = Jx + 2 * sizeof(T);
-    const char* const Jr = Jx + 3 * sizeof(T);
     auto issue_entries = [&](unsigned byte_offset, unsigned base, unsigned comp_bytes) {
-        load_to_lds_b32(Jx, byte_offset, base);
-        load_to_lds_b32(Jy, byte_offset, base + comp_bytes);
-        load_to_lds_b32(Jm, byte_offset, base + 2 * comp_bytes);
-        if (any_radius) load_to_lds_b32(Jr, byte_offset, base + 3 * comp_bytes);
+        load_to_lds_b32<0>(J, byte_offset, base);
+        load_to_lds_b32<4>(J, byte_offset, base + comp_bytes);
+        load_to_lds_b32<8>(J, byte_offset, base + 2 * comp_bytes);
+        if (any_radius) load_to_lds_b32<12>(J, byte_offset, base + 3 * comp_bytes);
     };
     auto issue_window = [&](long long st, int buf) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0][0]));
@@ -829,13 +828,24 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         return Rec<T>{comp0[idx], comp0[stride + idx], comp0[2 * stride + idx], any_radius ? comp0[3 * stride + idx] : 0.0f};
     };
     // after the loads have landed: are all coordinates of the window bounded, is some radius not +0.0f
-    struct WindowState { bool fast, rnz; };
-    auto check_window = [&](int kind, int kk, int buf) -> WindowState {
-        if (kind != 1) return WindowState{false, true};    // (a truncated tile is waited for where it is read)
+    // The collision screen of a fast turn needs an upper bound of the radii the window holds.  The window's bodies are
+    // J[st .. st + 127] (wrapped at N): they lie in the aligned tiles st / 128 and st / 128 + 1 and, when wrapped, tile 0;
+    // unpack_slots keeps max |radius| per aligned tile.  Scalar loads, issued with the window a turn ahead.
+    auto window_rmax = [&](long long st) -> float {
+        if (!any_radius) return 0.0f;
+        const int ta = __builtin_amdgcn_readfirstlane((int)(st / kTile));
+        const float ra = tile_rmax[ta], rb = tile_rmax[ta + 1];
+        const float rw = (st + kTile > N) ? tile_rmax[0] : 0.0f;
+        const float rab = ra > rb ? ra : rb;
+        return rab > rw ? rab : rw;
+    };
+    struct WindowState { bool fast; float rmax; };
+    auto check_window = [&](int kind, int kk, int buf, long long st_w) -> WindowState {
+        if (kind != 1) return WindowState{false, 0.0f};    // (a truncated tile is waited for where it is read)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // issued a whole turn ago
         __builtin_amdgcn_wave_barrier();
         // the whole replica is bounded (Meta::summary): no scan of the window; all its radii are +0 or not, globally
-        if (all_bounded) return WindowState{wave_ok && fast_tile(kk), any_radius};
+        if (all_bounded) return WindowState{wave_ok && fast_tile(kk), window_rmax(st_w)};
         Rec<T> r0{0, 0, 0, 0}, r1{0, 0, 0, 0};
         if (l < nwin) r0 = window_record(&win[w][buf][0][0], kWin, l);
         if (l + kWave < nwin) r1 = window_record(&win[w][buf][0][0], kWin, l + kWave);
@@ -843,12 +853,15 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const bool bad1 = !((abs_(r1.x) < kCoordBound) && (abs_(r1.y) < kCoordBound));
         WindowState ws;
         ws.fast = __ballot(bad0 || bad1) == 0ull && wave_ok && fast_tile(kk);
-        // some radius of the window is not +0.0f (see the one-lane kernel: with all radii +0 the flag threshold is 2^-80)
-        ws.rnz = __ballot(not_plus_zero(r0.r) || not_plus_zero(r1.r)) != 0ull;
+        ws.rmax = window_rmax(st_w);
         return ws;
     };
     // the general code on this turn's walk positions, records from the window (kind 1) / the whole tile (kind 2)
-    auto general_turn = [&](int kind, int kk, long long st, int L, int off0, int buf) {
+    // `bounded`: the window passed the coordinate check (a fast turn redone for a flagged lane): a pair that is no
+    // collision and not closer than 2^-40 then takes the scalar form of the fast chain - the same bits as the general
+    // code's IEEE square root and reciprocal (nbody_selftest_ieee_f32) at a quarter of the instructions; a flagged
+    // lane holds up its whole ring, so this path is worth keeping short.
+    auto general_turn = [&](int kind, int kk, long long st, int L, int off0, int buf, bool bounded) {
         if (kind == 2) {                                   // issued after the previous own turn's hand-off
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -870,6 +883,17 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             }
             const Rec<T> rec = kind == 1 ? window_record(&win[w][buf][0][0], kWin, (lit ? l : 0) + (off - off0))
                                          : window_record(whole, kTile, sidx);
+            if (bounded) {
+                const T dx = rec.x - a.xi, dy = rec.y - a.yi;
+                const T d2 = (dx * dx) + (dy * dy);
+                const T rs = a.ri + rec.r;
+                if (!(d2 <= fma_(rs, rs, kFastLo))) {      // no collision, inside the proved domain
+                    const T inv = fast_chain(d2).inv;
+                    a.fx = a.fx + (dx * rec.m) * inv;
+                    a.fy = a.fy + (dy * rec.m) * inv;
+                    continue;
+                }
+            }
             interact<T, kLog>(a, rec, p.growth, i, (int)j, ev, ev_cap, ctr, step);
         }
     };
@@ -891,7 +915,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     int kind = turn_kind(w, st);
     if (kind == 1) issue_window(st, buf);
     if (kind == 2) issue_truncated(st, tile_len(w / kTurnsPerTile, st));
-    WindowState cur = check_window(kind, w / kTurnsPerTile, buf);
+    WindowState cur = check_window(kind, w / kTurnsPerTile, buf, st);
     for (int tau = w; tau < nturns; tau += kW) {
         unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
         if (kProbe) pt0 = __builtin_readcyclecounter();
@@ -920,54 +944,41 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             const float* wx = &win[w][buf][0][lit ? l : 0];
             const float* wy = wx + kWin;
             const float* wm = wx + 2 * kWin;
-            int r_at = 3 * kWin;                           // beyond the reach of wx's immediate offsets: its own base
-            asm("" : "+v"(r_at));                          // register (hipcc otherwise recomputes the address per read)
-            const float* wr = wx + r_at;
             const V2 ownx = {a.xi, a.xi}, owny = {a.yi, a.yi};
-            float closest = kFastHi;                       // zero-radius path: the smallest d2 of the turn, per lane
-            auto evaluate = [&](auto r0_tag) {
-                constexpr bool kR0 = decltype(r0_tag)::value;
+            // Collision / tiny-distance screen, half an instruction per pair: a pair may only take the fast chain if it is
+            // no collision, d2 > (ri + rj)^2, and d2 > 2^-80 (the proved domain).  With R = |ri| + (largest |radius| the
+            // window can hold) every such pair has d2 > fma(R, R, 2^-80), a per-LANE constant of the turn, so the
+            // SMALLEST d2 of the lane's kT pairs decides for all of them (d2 is finite here - the coordinates are
+            // bounded - so no NaN can hide in the minimum; a NaN radius never collides and is not in the bound).  A
+            // lane below the threshold is redone by the general code, which applies the exact predicate.
+            const float reach = abs_(a.ri) + cur.rmax;
+            const float threshold = __builtin_fmaf(reach, reach, kFastLo);
+            float closest = kFastHi;
 #pragma unroll
-                for (int r0 = 0; r0 < kT; r0 += 4) {       // four walk positions per batch of reads: a, a, b, b
-                    const V2 xa = {wx[r0], wx[r0 + 1]}, xb = {wx[r0 + 2], wx[r0 + 3]};
-                    const V2 ya = {wy[r0], wy[r0 + 1]}, yb = {wy[r0 + 2], wy[r0 + 3]};
-                    const V2 ma = {wm[r0], wm[r0 + 1]}, mb = {wm[r0 + 2], wm[r0 + 3]};
-                    V2 ra = {0.0f, 0.0f}, rb = {0.0f, 0.0f};
-                    if (!kR0) { ra = V2{wr[r0], wr[r0 + 1]}; rb = V2{wr[r0 + 2], wr[r0 + 3]}; }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const V2 dxa = xa - ownx, dxb = xb - ownx;
-                    const V2 dya = ya - owny, dyb = yb - owny;
-                    const V2 sxa = dxa * dxa, sxb = dxb * dxb;
-                    const V2 sya = dya * dya, syb = dyb * dyb;
-                    const V2 d2a = sxa + sya, d2b = sxb + syb;   // three roundings per element (no contraction in this file)
-                    if (kR0) {
-                        // all radii +0: the threshold is 2^-80 for every pair, so ONE comparison of the turn's
-                        // smallest d2 decides (half an instruction per pair; d2 is finite here - the coordinates
-                        // are bounded - so no NaN can hide in the minimum)
-                        const float first_d2 = (r0 == 0 && first) ? kFastHi : d2a.x;
-                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(first_d2), "v"(d2a.y));
-                        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2b.x), "v"(d2b.y));
-                    } else {
-                        const V2 ri2 = {a.ri, a.ri}, lo2 = {kFastLo, kFastLo};
-                        const V2 rsa = ri2 + ra, rsb = ri2 + rb;
-                        const V2 qa = __builtin_elementwise_fma(rsa, rsa, lo2), qb = __builtin_elementwise_fma(rsb, rsb, lo2);
-                        const unsigned long long close_a = le_mask(d2a.x, qa.x);   // flag only
-                        flag |= (r0 == 0 && first) ? 0ull : close_a;
-                        flag |= le_mask(d2a.y, qa.y);
-                        flag |= le_mask(d2b.x, qb.x);
-                        flag |= le_mask(d2b.y, qb.y);
-                    }
-                    V2 inva, invb;
-                    fast_inv_cube2x2(d2a, d2b, inva, invb);
-                    const V2 txa = dxa * ma, txb = dxb * mb;
-                    const V2 tya = dya * ma, tyb = dyb * mb;
-                    termx[r0 / 2] = txa * inva; termx[r0 / 2 + 1] = txb * invb;
-                    termy[r0 / 2] = tya * inva; termy[r0 / 2 + 1] = tyb * invb;
-                }
-                if (kR0) flag = le_mask(closest, kFastLo);
-            };
-            if (wave_r0 && !cur.rnz) evaluate(std::true_type{});
-            else evaluate(std::false_type{});
+            for (int r0 = 0; r0 < kT; r0 += 4) {           // four walk positions per batch of reads: a, a, b, b
+                const V2 xa = {wx[r0], wx[r0 + 1]}, xb = {wx[r0 + 2], wx[r0 + 3]};
+                const V2 ya = {wy[r0], wy[r0 + 1]}, yb = {wy[r0 + 2], wy[r0 + 3]};
+                const V2 ma = {wm[r0], wm[r0 + 1]}, mb = {wm[r0 + 2], wm[r0 + 3]};
+                __builtin_amdgcn_sched_barrier(0);
+                const V2 dxa = xa - ownx, dxb = xb - ownx;
+                const V2 dya = ya - owny, dyb = yb - owny;
+                const V2 sxa = dxa * dxa, sxb = dxb * dxb;
+                const V2 sya = dya * dya, syb = dyb * dyb;
+                const V2 d2a = sxa + sya, d2b = sxb + syb; // three roundings per element (no contraction in this file)
+                const float first_d2 = (r0 == 0 && first) ? kFastHi : d2a.x;   // the self position is no pair
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(first_d2), "v"(d2a.y));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2b.x), "v"(d2b.y));
+                V2 inva, invb;
+                fast_inv_cube2x2(d2a, d2b, inva, invb);
+                const V2 txa = dxa * ma, txb = dxb * mb;
+                const V2 tya = dya * ma, tyb = dyb * mb;
+                termx[r0 / 2] = txa * inva; termx[r0 / 2 + 1] = txb * invb;
+                termy[r0 / 2] = tya * inva; termy[r0 / 2 + 1] = tyb * invb;
+                // the terms are finished HERE (hipcc otherwise sinks the last multiply into the blocks that add them up
+                // and keeps both factors alive until then: twice the registers, spills)
+                asm volatile("" : "+v"(termx[r0 / 2]), "+v"(termx[r0 / 2 + 1]), "+v"(termy[r0 / 2]), "+v"(termy[r0 / 2 + 1]));
+            }
+            flag = le_mask(closest, threshold);
             // the reference skips the self position; the sum starts at +0.0f and +0 + +0 = +0: adding a zero term is
             // the same bits (whatever the self "pair" evaluated to is dropped here)
             if (first) { termx[0].x = 0.0f; termy[0].x = 0.0f; }
@@ -996,7 +1007,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         // (x and y chains interleaved: scalar adds need no wait states between dependent instructions, packed ones
         // do), then one LDS write; `flags` passes through untouched.
         const bool plain = fast && flag == 0ull && !dead && !timed_out && __ballot(h.z != tau) == 0ull;
-        if (plain) {
+        if (__builtin_expect(plain, 1)) {
             float fx = __int_as_float(h.x), fy = __int_as_float(h.y);
 #pragma unroll
             for (int r = 0; r < kT; ++r) {
@@ -1017,22 +1028,71 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             dead = dead || timed_out || __ballot(h.z >= kRingDeadSeq) != 0ull;
             const unsigned m_before = __float_as_uint(a.mnew), r_before = __float_as_uint(a.rnew);
             if (fast) {
+                // The flagged lanes (a SUPERSET of the lanes with a collision or a tiny distance in this turn) get the exact
+                // status of each of their kT pairs, and they get it in parallel: lane r of the wave evaluates walk position r
+                // of flagged lane fl's body from the same window.  `hits`: positions that are collisions the reference
+                // handles and moves on from (:215-226: no force term); `odd`: some pair inside the guard that is not
+                // such a collision (tiny distance, the 2^-80 margin, a NaN mass) - that lane is redone by the general code.
+                unsigned hits = 0;
+                bool odd = false;
+                unsigned long long todo = flag & __ballot(active);
+                while (todo != 0ull) {
+                    const int fl = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+                    todo &= todo - 1ull;
+                    const T xf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.xi), fl));
+                    const T yf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.yi), fl));
+                    const T mf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.mi), fl));
+                    const T rf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.ri), fl));
+                    const int r = l & (kT - 1);
+                    const Rec<T> rec = window_record(&win[w][buf][0][0], kWin, (lit ? fl : 0) + r);
+                    const T dx = rec.x - xf, dy = rec.y - yf;
+                    const T d2 = (dx * dx) + (dy * dy);
+                    const T rs = rf + rec.r;
+                    const bool is_pair = l < kT && !(first && r == 0);          // walk position 0 of tile 0 is the body itself
+                    const bool hit = d2 <= rs * rs && (mf >= rec.m || mf < rec.m); // interact(): `hit && (ge || lt)`
+                    const bool guarded = d2 <= fma_(rs, rs, kFastLo);              // what the fast chain must not see
+                    const unsigned long long hm = __ballot(is_pair && hit);
+                    const unsigned long long om = __ballot(is_pair && guarded && !hit);
+                    if (l == fl) { hits = (unsigned)hm; odd = om != 0ull; }
+                }
                 if (active) {
-                    if ((flag >> l) & 1ull) {
-                        general_turn(1, kk, st, L, off0, buf);
+                    if (odd) {
+                        general_turn(1, kk, st, L, off0, buf, true);
                     } else {
                         float fx = a.fx, fy = a.fy;
 #pragma unroll
                         for (int r = 0; r < kT; ++r) {
-                            fx = add_unmerged(fx, (r & 1) ? termx[r / 2].y : termx[r / 2].x);
-                            fy = add_unmerged(fy, (r & 1) ? termy[r / 2].y : termy[r / 2].x);
+                            const float nx = add_unmerged(fx, (r & 1) ? termx[r / 2].y : termx[r / 2].x);
+                            const float ny = add_unmerged(fy, (r & 1) ? termy[r / 2].y : termy[r / 2].x);
+                            const bool skip = ((hits >> r) & 1u) != 0u;            // a collision adds no force term (not even +0)
+                            fx = skip ? fx : nx;
+                            fy = skip ? fy : ny;
                         }
                         a.fx = fx; a.fy = fy;
+                        unsigned rest = hits;                                      // the collisions themselves, in walk order
+                        while (rest != 0u) {
+                            const int r = __builtin_ctz(rest);
+                            rest &= rest - 1u;
+                            const Rec<T> rec = window_record(&win[w][buf][0][0], kWin, (lit ? l : 0) + r);
+                            const bool ge = a.mi >= rec.m;
+                            if (ge) {                                              // :215-221
+                                a.mnew = a.mnew + rec.m;
+                                a.rnew = a.rnew + rec.r * p.growth;
+                            } else {                                               // :222-226
+                                a.deleted = 1;
+                            }
+                            if (kLog) {
+                                long long j = lit ? st + ((t + off0 + r) & (kTile - 1)) : st + off0 + r;
+                                if (j >= N) j %= N;
+                                const unsigned long long slot = atomicAdd(&ctr->events, 1ull);
+                                if (slot < (unsigned long long)ev_cap) ev[slot] = Event{step, i, (int)j, ge ? 0 : 1};
+                            }
+                        }
                     }
                     pairs += kT - (first ? 1 : 0);
                 }
             } else if (active) {
-                general_turn(kind, kk, st, L, off0, buf);
+                general_turn(kind, kk, st, L, off0, buf, false);
                 const int hi = off0 + kT < L ? off0 + kT : L;
                 if (lit) {
                     if (hi > off0) pairs += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
@@ -1061,7 +1121,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         buf ^= 1;
         st = st_next;
         kind = kind_next;
-        cur = check_window(kind, (tau + kW) / kTurnsPerTile, buf);
+        cur = check_window(kind, (tau + kW) / kTurnsPerTile, buf, st);
         if (kProbe) {
             pr_eval += pt1 - pt0; pr_wait += pt2 - pt1; pr_chain += pt3 - pt2;
             pr_check += __builtin_readcyclecounter() - pt3;
@@ -1115,11 +1175,13 @@ constexpr int kCompactBlock = 1024;
 template <typename T>
 __global__ __launch_bounds__(kCompactBlock) void compact_count(const Rec<T>* __restrict__ S_J,
                                                                const Meta* __restrict__ meta,
-                                                               int* __restrict__ blk_counts) {
+                                                               int* __restrict__ blk_counts,
+                                                               unsigned* __restrict__ tile_rmax, int n_tiles) {
     __shared__ int wsum[kCompactBlock / kWave];
     const int cnt = meta->cnt;
     const int q = blockIdx.x * kCompactBlock + threadIdx.x;
     if (q == 0) const_cast<Meta*>(meta)->summary = 0;      // the force kernel of this step is done with it
+    for (int k = q; k < n_tiles; k += gridDim.x * kCompactBlock) tile_rmax[k] = 0u;   // ... and with these: unpack_slots refills
     const bool keep = q < cnt && S_J[q].m != (T)0;
     const unsigned long long bal = __ballot(keep);
     if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = __popcll(bal);
@@ -1189,7 +1251,8 @@ __global__ __launch_bounds__(kCompactBlock) void compact_scatter(const Rec<T>* _
 template <typename T>
 __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restrict__ gather, size_t slot_bytes,
                                                     int cap_own, int world, int rank, Rec<T>* __restrict__ J,
-                                                    Vec2<T>* __restrict__ Vown, Meta* __restrict__ meta) {
+                                                    Vec2<T>* __restrict__ Vown, Meta* __restrict__ meta,
+                                                    unsigned* __restrict__ tile_rmax) {
     const int g = blockIdx.y;
     int off = 0, total = 0;
     for (int h = 0; h < world; ++h) {
@@ -1205,6 +1268,7 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
     const Vec2<T>* vels = reinterpret_cast<const Vec2<T>*>(slot + sizeof(SlotHeader) + (size_t)cap_own * sizeof(Rec<T>));
     const int q = blockIdx.x * 256 + threadIdx.x;
     int bits = 0;
+    unsigned rbits = 0;                                    // bits of |radius| (non-negative floats order like unsigned)
     if (q < c) {
         const Rec<T> r = recs[q];
         const int i = off + q;                             // index of this body in step t+1
@@ -1212,6 +1276,25 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         if (i >= lo && i < lo + cnt) Vown[i - lo] = vels[q];
         const bool bounded = abs_(r.x) < FastDomain<T>::coord && abs_(r.y) < FastDomain<T>::coord;
         bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
+        const float ar = (float)abs_(r.r);
+        rbits = (ar == ar) ? __float_as_uint(ar) : 0u;      // a NaN radius never collides (the predicate is false): skipped
+    }
+    // Largest |radius| per aligned 128-body tile of the new replica, for the ring kernel's collision screen.  The 64
+    // lanes of a wave hold consecutive bodies, i.e. at most two tiles: one wave reduction per tile, two atomics per wave.
+    {
+        const int i0 = off + blockIdx.x * 256 + (int)(threadIdx.x & ~(kWave - 1u));   // body of this wave's lane 0
+        const int t0 = i0 / kTile;
+        const bool in_t0 = (off + q) / kTile == t0;
+        unsigned m0 = in_t0 ? rbits : 0u, m1 = in_t0 ? 0u : rbits;
+        for (int sh = kWave / 2; sh > 0; sh >>= 1) {
+            const unsigned o0 = __shfl_xor(m0, sh, kWave), o1 = __shfl_xor(m1, sh, kWave);
+            m0 = o0 > m0 ? o0 : m0;
+            m1 = o1 > m1 ? o1 : m1;
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            if (m0 != 0u) atomicMax(&tile_rmax[t0], m0);
+            if (m1 != 0u) atomicMax(&tile_rmax[t0 + 1], m1);
+        }
     }
     const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
                           (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0);

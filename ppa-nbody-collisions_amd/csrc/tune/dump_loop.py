@@ -8,7 +8,7 @@ import sys
 s = open("/root/repo/build/csrc/nbody_ctx.s").read()
 sub = sys.argv[1]
 lines = s.split("\n")
-starts = [k for k, l in enumerate(lines) if l.startswith("_ZN") and sub in l and ": " in l and l.split(":")[0].endswith("E")]
+starts = [k for k, l in enumerate(lines) if l.startswith("_ZN") and sub in l and ": ;" in l]
 k0 = starts[0]
 k1 = next(k for k in range(k0, len(lines)) if lines[k].startswith(".Lfunc_end"))
 body = "\n".join(lines[k0:k1])
