@@ -318,6 +318,45 @@ def test_extreme_values_take_the_general_path(nb, variant):
     st.close()
 
 
+@pytest.mark.parametrize("variant", [0, 50, 52, 54, 31])
+@pytest.mark.parametrize("n", [3000, 4096])
+def test_collision_screen_radius_bounds(nb, variant, n):
+    """The ring kernel screens a turn for collisions with ONE threshold per lane, fma(R, R, 2^-80), R = |ri| + the largest
+    |radius| of the aligned 128-body tiles the window touches (kept per tile by nbody_upload / unpack_slots); flagged
+    lanes then get the exact status of their pairs.  Bounded coordinates, so that path is the one in use.  A giant, a
+    negative, a NaN, an infinite and a denormal radius, a giant in the last (partial, wrapped-into) tile, a NaN mass
+    inside a giant's reach (a hit the reference's if / else-if does not handle: the force term stays), over enough steps
+    for deletions to move bodies from tile to tile; N = 3000 makes windows straddle two tiles and wrap."""
+    field = 20000
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg)
+    P, M, R = bodies.Positions, bodies.Masses, bodies.Radii
+    R[10] = 3000.0
+    P[12] = P[10] + np.float32([100.0, 0.0])
+    M[12] = np.nan
+    R[200] = -400.0
+    R[777] = np.nan
+    R[1500] = 1e-42
+    R[2100] = np.inf
+    R[n - 1] = 2500.0
+    R[130:140] = 60.0
+    st = nb.Stepper(cfg, kernel_variant=variant, record_events=True, event_capacity=1 << 20)
+    st.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    for s in range(5):
+        st.step(1)
+        cur, stats, ab, de, _ = ol.port_step(blk, cur, DT, field, field, GROWTH)
+        ev = st.events()
+        ev = ev[ev["step"] == s]
+        assert sorted((int(e["i"]), int(e["j"])) for e in ev[ev["kind"] == 0]) == \
+            sorted((int(x), int(y)) for x, y in ab), "E_t step %d" % s
+        assert sorted(set(int(e["i"]) for e in ev[ev["kind"] == 1])) == sorted(int(x) for x in de), "D_t step %d" % s
+        out = st.download()
+        assert out.numBodies == cur and _nan_aware_equal(out.block, blk[:6 * cur]), "step %d" % s
+    st.close()
+
+
 @pytest.mark.parametrize("variant", [0, 11, 50, 52])
 def test_unbounded_tile_mid_walk(nb, variant):
     """A tile with an out-of-range coordinate in the MIDDLE of every other body's walk (not in their own block):
