@@ -867,6 +867,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             __builtin_amdgcn_wave_barrier();
         }
         const int hi = off0 + kT < L ? off0 + kT : L;
+        int lane_entry = lit ? l : 0;                      // this lane's first window entry.  Computed HERE: hoisted out of
+        asm volatile("" : "+v"(lane_entry));               // the turn loop it is one more register the fast path cannot spare
 #pragma unroll 1
         for (int off = off0; off < hi; ++off) {
             int sidx;
@@ -881,7 +883,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 j = st + off;
                 if (j == i64) continue;
             }
-            const Rec<T> rec = kind == 1 ? window_record(&win[w][buf][0][0], kWin, (lit ? l : 0) + (off - off0))
+            const Rec<T> rec = kind == 1 ? window_record(&win[w][buf][0][0], kWin, lane_entry + (off - off0))
                                          : window_record(whole, kTile, sidx);
             if (bounded) {
                 const T dx = rec.x - a.xi, dy = rec.y - a.yi;
@@ -1070,10 +1072,12 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                         }
                         a.fx = fx; a.fy = fy;
                         unsigned rest = hits;                                      // the collisions themselves, in walk order
+                        int lane_entry = lit ? l : 0;
+                        asm volatile("" : "+v"(lane_entry));                       // (see general_turn)
                         while (rest != 0u) {
                             const int r = __builtin_ctz(rest);
                             rest &= rest - 1u;
-                            const Rec<T> rec = window_record(&win[w][buf][0][0], kWin, (lit ? l : 0) + r);
+                            const Rec<T> rec = window_record(&win[w][buf][0][0], kWin, lane_entry + r);
                             const bool ge = a.mi >= rec.m;
                             if (ge) {                                              // :215-221
                                 a.mnew = a.mnew + rec.m;
