@@ -653,7 +653,9 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 // runs half empty: see the priority rule at the top of the loop.  (c) Every turn reads from the window: tile 0 is a
 // fast tile whose self position is masked, the truncated last tile is loaded whole across both window buffers.
 // (d) Meta::summary says whether ANY coordinate of the replica is unbounded / any radius non-zero: windows are scanned
-// only then.
+// only then.  (e) One evaluation path for every radius: the collision / tiny-distance screen is the smallest d2 of a
+// lane's kT pairs against ONE threshold from the largest |radius| of the tiles the window touches (tile_rmax, kept by
+// unpack_slots); flagged lanes get the exact status of their pairs in parallel across the wave (see the turn loop).
 // A wait that exceeds p.spin_limit polls is reported (Counters::errors, sticky on the host) and POISONS the chain:
 // the state becomes NaN and a dead mark travels with the sequence number, so every later turn passes at once and
 // the step's output cannot be mistaken for a result.
