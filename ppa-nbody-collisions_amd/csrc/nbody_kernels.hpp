@@ -312,13 +312,15 @@ __device__ __forceinline__ FastChainD fast_chain(double x) {
     const double d1 = __builtin_fma(-g2, g2, x);
     const double d = __builtin_fma(d1, h1, g2);
     const double c = (d * d) * d;
-    const double q0 = __builtin_amdgcn_rcp(c);
+    // 1 / c without a second transcendental (v_rcp_f64 costs about five fp64 multiplies on this chip): h1 is 1 / (2 sqrt x)
+    // to ~2^-50, so 8 h1^3 is 1 / c to ~2^-47 - a far better seed than the instruction's ~2^-26 - and ONE Newton step plus
+    // the final residual correction of the compiler's own expansion (the step that makes its result correctly rounded:
+    // after it the error is the square of a half-ulp residual) replace the instruction and two of its three steps.
+    const double q0 = ((h1 * h1) * h1) * 8.0;
     const double e0 = __builtin_fma(-c, q0, 1.0);
     const double q1 = __builtin_fma(q0, e0, q0);
     const double e1 = __builtin_fma(-c, q1, 1.0);
-    const double q2 = __builtin_fma(q1, e1, q1);
-    const double e2 = __builtin_fma(-c, q2, 1.0);
-    return FastChainD{d, __builtin_fma(e2, q2, q2)};
+    return FastChainD{d, __builtin_fma(e1, q1, q1)};
 }
 
 // Two chains at once on 2-vectors, element-wise (the same operations per element as fast_chain, hence the same
