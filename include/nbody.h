@@ -248,8 +248,11 @@ void* nbody_ctx_stream(nbody_ctx* ctx);   /* hipStream_t of the context */
  * velocities are updated in place, updatedMasses/updatedRadii are the scratch arrays of :463-464.  The
  * never-allocated `updatedVelocities` argument of the reference (:441) is dropped.  `stream` is a
  * hipStream_t (NULL = default stream).  numBlocks follows :473; pass nbody_num_blocks(numBodies): with that
- * block count the production kernel runs on the block layout (same speed as nbody_step); any other count is
- * honoured by a general kernel (it changes which bodies are active and how many tiles are walked).
+ * block count the production kernel of nbody_step runs (same speed), through a process-wide workspace on the current
+ * device that holds what a context keeps resident (the {x,y,m,r} replica and the staged output; grown to the largest
+ * numBodies seen, released by nbody_launch_workspace_release; not re-entrant, as the reference's loop is one host
+ * thread); any other count is honoured by a general kernel directly on the block (it changes which bodies are
+ * active and how many tiles are walked).
  * ------------------------------------------------------------------------------------------------- */
 int nbody_num_blocks(int numBodies);      /* src/nbody.cu:473 */
 int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updatedMasses, float* d_updatedRadii,
@@ -257,6 +260,7 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updatedMasses, fl
                                     int numBlocks, float growthRate, void* stream);
 int nbody_launch_move_bodies_f32(void* d_bodyData, const float* d_updatedMasses, const float* d_updatedRadii,
                                  int numBodies, float timestep, int numBlocks, void* stream);
+int nbody_launch_workspace_release(void);   /* frees the workspace of nbody_launch_compute_forces_f32 (if any) */
 
 /* Device self-test used by the GPU test-suite, exhaustive over all 2^32 fp32 inputs: the kernels' general
  * sqrt and reciprocal against fp64-then-round, and the fast evaluation chain of the fp32 force kernel

@@ -124,6 +124,7 @@ SYMBOLS = {
     "nbody_num_blocks": (_i, [_i]),
     "nbody_launch_compute_forces_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _i, _i, _f, _vp]),
     "nbody_launch_move_bodies_f32": (_i, [_vp, _vp, _vp, _i, _f, _i, _vp]),
+    "nbody_launch_workspace_release": (_i, []),
     "nbody_selftest_ieee_f32": (_i, [_i, ctypes.POINTER(ctypes.c_uint64 * 3)]),
     "nbody_selftest_chain_f64": (_i, [_i, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64 * 2)]),
     "nbody_selftest_lds_record": (_i, [_i, _i, ctypes.POINTER(ctypes.c_uint64 * 3)]),

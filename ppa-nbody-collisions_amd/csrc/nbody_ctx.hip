@@ -861,6 +861,36 @@ int nbody_get_stats(nbody_ctx* c, nbody_stats* out) {
 // ---------------------------------------------------------------------------------------------------------
 // Reference-shaped launches (src/nbody.cu:481-483)
 // ---------------------------------------------------------------------------------------------------------
+// Workspace of the reference-shaped launch: a context on the CURRENT device, grown to the largest body count seen.
+// Process-wide and not re-entrant, like the reference's own loop (one host thread, src/nbody.cu:373).
+namespace {
+nbody_ctx* g_ref_ws = nullptr;
+int g_ref_ws_device = -1;
+int ref_launch_workspace(int n, nbody_ctx** out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (g_ref_ws && (g_ref_ws_device != dev || g_ref_ws->cap < n)) {
+        nbody_ctx_destroy(g_ref_ws);
+        g_ref_ws = nullptr;
+    }
+    if (!g_ref_ws) {
+        nbody_ctx_desc d{};
+        d.precision = NBODY_F32; d.semantics = NBODY_LITERAL; d.capacity = n; d.device = dev; d.rank = 0; d.world = 1;
+        d.event_capacity = 16;
+        int rc = nbody_ctx_create(&g_ref_ws, &d);
+        if (rc != NBODY_OK) return rc;
+        g_ref_ws_device = dev;
+    }
+    *out = g_ref_ws;
+    return NBODY_OK;
+}
+}  // namespace
+
+int nbody_launch_workspace_release(void) {
+    if (g_ref_ws) { nbody_ctx_destroy(g_ref_ws); g_ref_ws = nullptr; g_ref_ws_device = -1; }
+    return NBODY_OK;
+}
+
 int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_updR, int numBodies,
                                     float timestep, int fieldWidth, int fieldHeight, int numBlocks,
                                     float growthRate, void* stream) {
@@ -871,10 +901,37 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_up
     d.semantics = NBODY_LITERAL;
     const StepParams<float> p = make_params<float>(d);
     const char* force_general = getenv("NBODY_REF_LAUNCH_GENERAL");        // testing aid
-    if (numBlocks == nbody_num_blocks(numBodies) && !(force_general && force_general[0] == '1')) {
-        // the reference's own launch geometry (src/nbody.cu:473): the production kernel on the block layout.
-        // One 128-lane group per started 128-body block (two per workgroup); bodies past the last full block get no thread in the
-        // reference and are left untouched here too.
+    const char* one_lane = getenv("NBODY_REF_LAUNCH_ONE_LANE");            // testing aid
+    if (numBlocks == nbody_num_blocks(numBodies) && !(force_general && force_general[0] == '1') &&
+        !(one_lane && one_lane[0] == '1')) {
+        // the reference's own launch geometry (src/nbody.cu:473): the production (ring) kernel, through a process-wide
+        // workspace that holds the {x,y,m,r} replica and the staged output - what a context keeps resident.  Bodies
+        // past the last full block get no thread in the reference and are left untouched here too.
+        nbody_ctx* c = nullptr;
+        int rc = ref_launch_workspace(numBodies, &c);
+        if (rc != NBODY_OK) return rc;
+        hipStream_t s = (hipStream_t)stream;
+        HIP_TRY(hipMemsetAsync(c->meta, 0, sizeof(Meta), s));
+        HIP_TRY(hipMemsetAsync(c->tile_rmax, 0, sizeof(unsigned) * (size_t)c->n_tiles, s));
+        hipLaunchKernelGGL(ref_layout_pack_f32, dim3((numBodies + 255) / 256), dim3(256), 0, s, (const void*)d_bodyData,
+                           numBodies, (Rec<float>*)c->J, c->meta, c->tile_rmax);
+        // aim the workspace at the caller's stream and at the velocities where they lie in the block
+        const hipStream_t own_stream = c->stream;
+        void* const own_vel = c->Vown;
+        c->stream = s;
+        c->Vown = (float*)d_bodyData + 2 * (size_t)numBodies;
+        c->own_upper = c->n_upper = numBodies;
+        StepParams<float> pr = p;
+        pr.spin_limit = c->spin_limit;
+        launch_forces<float>(c, pr, numBodies / kTile > 0 ? numBodies / kTile : 1, false);
+        c->stream = own_stream;
+        c->Vown = own_vel;
+        const int n_active = numBodies < kTile ? numBodies : (numBodies / kTile) * kTile;
+        hipLaunchKernelGGL(ref_layout_finish_f32, dim3((n_active + 255) / 256), dim3(256), 0, s, d_bodyData, d_updM, d_updR,
+                           numBodies, n_active, (const Rec<float>*)c->S_J, (const Vec2<float>*)c->S_V);
+    } else if (numBlocks == nbody_num_blocks(numBodies) && !(force_general && force_general[0] == '1')) {
+        // NBODY_REF_LAUNCH_ONE_LANE=1: the one-lane-per-body kernel directly on the block layout, no workspace (round 1's
+        // form of this launch; kept as a second implementation the tests compare)
         hipLaunchKernelGGL(ref_layout_forces_v3_f32, dim3((numBodies / kTile + 2) / 2), dim3(2 * kTile), 0,
                            (hipStream_t)stream, d_bodyData, d_updM, d_updR, numBodies, p);
     } else {

@@ -1378,6 +1378,55 @@ __global__ __launch_bounds__(kTile) void ref_layout_forces_f32(void* bodyData, f
     }
 }
 
+// The reference-shaped launch through the ring kernel (nbody_launch_compute_forces_f32 with the reference's own block
+// count): the device block [P|V|M|R] is packed into the {x,y,m,r} replica of a process-wide workspace - with Meta and
+// the per-tile radius bounds exactly as nbody_upload / unpack_slots produce them -, the ring kernel reads the
+// velocities where they lie in the block, and its staged output is written back in the reference's form:
+// velocities in place, updatedMasses / updatedRadii (src/nbody.cu:245-246,264).  meta and tile_rmax are zeroed before.
+__global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData, int N, Rec<float>* __restrict__ J,
+                                                           Meta* __restrict__ meta, unsigned* __restrict__ tile_rmax) {
+    const Vec2<float>* P = reinterpret_cast<const Vec2<float>*>(bodyData);    // :147-150
+    const float* M = reinterpret_cast<const float*>(P + 2 * (size_t)N);
+    const float* R = M + N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int bits = 0;
+    unsigned rbits = 0;
+    if (i < N) {
+        const Vec2<float> pi = P[i];
+        const Rec<float> r{pi.x, pi.y, M[i], R[i]};
+        J[i] = r;
+        const bool bounded = abs_(r.x) < FastDomain<float>::coord && abs_(r.y) < FastDomain<float>::coord;
+        bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
+        const float ar = abs_(r.r);
+        rbits = (ar == ar) ? __float_as_uint(ar) : 0u;
+    }
+    for (int sh = kWave / 2; sh > 0; sh >>= 1) {           // a wave's 64 bodies lie in one aligned 128-body tile
+        const unsigned o = __shfl_xor(rbits, sh, kWave);
+        rbits = o > rbits ? o : rbits;
+    }
+    const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
+                          (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0);
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (rbits != 0u) atomicMax(&tile_rmax[i / kTile], rbits);
+        if (wave_bits != 0) atomicOr(&meta->summary, wave_bits);
+    }
+    if (i == 0) { meta->n = N; meta->lo = 0; meta->cnt = N; meta->step = 0; meta->n_prev = N; }
+}
+
+__global__ __launch_bounds__(256) void ref_layout_finish_f32(void* bodyData, float* __restrict__ updM,
+                                                             float* __restrict__ updR, int N, int n_active,
+                                                             const Rec<float>* __restrict__ S_J,
+                                                             const Vec2<float>* __restrict__ S_V) {
+    Vec2<float>* V = reinterpret_cast<Vec2<float>*>(bodyData) + N;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_active) {                                    // bodies past the last full block have no thread (:142-143, :473)
+        const Rec<float> out = S_J[i];
+        updM[i] = out.m;
+        updR[i] = out.r;
+        V[i] = S_V[i];
+    }
+}
+
 __global__ __launch_bounds__(kTile) void ref_layout_move_f32(void* bodyData, const float* __restrict__ updM,
                                                              const float* __restrict__ updR, int N, float dt) {
     Vec2<float>* P = reinterpret_cast<Vec2<float>*>(bodyData);                // :283-286

@@ -642,16 +642,18 @@ def test_full_size_sampled_parity_n262144(nb):
     st.close()
 
 
-@pytest.mark.parametrize("general", [False, True], ids=["production-kernel", "general-kernel"])
+@pytest.mark.parametrize("general", [0, 1, 2], ids=["production-kernel", "general-kernel", "one-lane-kernel"])
 @pytest.mark.parametrize("path", [p for p in STEP_FILES if "long_" not in p],
                          ids=[os.path.basename(p)[6:-4] for p in STEP_FILES if "long_" not in p])
 def test_reference_shaped_launches(nb, path, general, monkeypatch):
     """nbody_launch_compute_forces_f32 / nbody_launch_move_bodies_f32 on a caller-owned device block in the
     reference layout (drop-in for src/nbody.cu:481-483), followed by the host compaction, on every golden case;
-    device memory comes from torch.  With the reference's own block count the launch runs the production kernel
-    on the block layout; NBODY_REF_LAUNCH_GENERAL=1 forces the general kernel that serves other block counts."""
+    device memory comes from torch.  With the reference's own block count the launch runs the production (ring) kernel
+    through the launch workspace; NBODY_REF_LAUNCH_GENERAL=1 forces the general kernel that serves other block counts,
+    NBODY_REF_LAUNCH_ONE_LANE=1 the one-lane-per-body kernel directly on the block layout."""
     import torch
-    monkeypatch.setenv("NBODY_REF_LAUNCH_GENERAL", "1" if general else "0")
+    monkeypatch.setenv("NBODY_REF_LAUNCH_GENERAL", "1" if general == 1 else "0")
+    monkeypatch.setenv("NBODY_REF_LAUNCH_ONE_LANE", "1" if general == 2 else "0")
     z = np.load(path)
     dt, growth, fw, fh = z["params"]
     n = int(z["n0"])
