@@ -235,6 +235,8 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if world > 1 and ndev > 1 and world > ndev:
+        raise SystemExit("bench.py: %d ranks but only %d HIP devices visible (RCCL needs one device per rank)" % (world, ndev))
     local_rank %= ndev                 # a launcher that exposes one device per rank (HIP_VISIBLE_DEVICES)
 
     comm_id = None
