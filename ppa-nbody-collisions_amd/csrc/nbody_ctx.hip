@@ -106,6 +106,7 @@ struct nbody_ctx {
     size_t slot_bytes = 0;
     int* blk_counts = nullptr;
     unsigned* tile_rmax = nullptr;  // per aligned 128-body tile of J: bits of max |radius| (NaN skipped); see unpack_slots
+    float* Jt = nullptr;            // fp32 contexts: the replica once more, tile by tile component-major (see store_tiled)
     int n_tiles = 0;                // cap / 128 + 2
     Meta* meta = nullptr;
     Meta* meta_all = nullptr;       // RCCL contexts: every rank's Meta, all-gathered by nbody_download
@@ -252,8 +253,8 @@ void launch_v3w(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log)
 template <int kW, int kT, int kSleep, bool kProbe, int kRings>
 void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
     const int grid = (nblocks * 2 + kRings - 1) / kRings;  // a workgroup serves kRings rings of 64 bodies, two per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax);
-    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax);
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax, (const float*)c->Jt);
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax, (const float*)c->Jt);
 }
 template <>
 void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
@@ -344,7 +345,7 @@ int launch_commit(nbody_ctx* c) {
     const int gx_all = c->desc.world > 1 ? (c->cap_own + 255) / 256 : gx;
     hipLaunchKernelGGL((unpack_slots<T>), dim3(gx_all, c->desc.world), dim3(256), 0, c->stream,
                        (const unsigned char*)c->gather, c->slot_bytes, c->cap_own, c->desc.world, c->desc.rank,
-                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta, c->tile_rmax);
+                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta, c->tile_rmax, c->Jt);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
@@ -379,7 +380,7 @@ void free_all(nbody_ctx* c) {
     hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
     if (c->gather && c->gather != c->slot) hipFree(c->gather);
     hipFree(c->slot);
-    hipFree(c->blk_counts); hipFree(c->tile_rmax); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
+    hipFree(c->blk_counts); hipFree(c->tile_rmax); hipFree(c->Jt); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_meta) hipHostFree(c->h_meta);
     if (c->h_meta_async) hipHostFree(c->h_meta_async);
@@ -466,6 +467,10 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     c->n_tiles = c->cap / kTile + 2;
     CTX_TRY(hipMalloc((void**)&c->tile_rmax, sizeof(unsigned) * (size_t)c->n_tiles));
     CTX_TRY(hipMemset(c->tile_rmax, 0, sizeof(unsigned) * (size_t)c->n_tiles));
+    if (d->precision != NBODY_F64) {
+        CTX_TRY(hipMalloc((void**)&c->Jt, sizeof(float) * 4 * kTile * (size_t)c->n_tiles));
+        CTX_TRY(hipMemset(c->Jt, 0, sizeof(float) * 4 * kTile * (size_t)c->n_tiles));
+    }
     CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
     if (use_comm) CTX_TRY(hipMalloc((void**)&c->meta_all, sizeof(Meta) * (size_t)d->world));
     CTX_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
@@ -544,6 +549,8 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
             summary |= (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero_host(R[i]) ? kSummaryRadius : 0);
         }
         HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<float>), hipMemcpyHostToDevice, c->stream));
+        if (n > 0) hipLaunchKernelGGL(records_to_tiles_f32, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                                      (const Rec<float>*)c->J, n, c->Jt);
         HIP_TRY(hipMemcpyAsync(c->Vown, V + 2 * (size_t)lo, (size_t)cnt * 8, hipMemcpyHostToDevice, c->stream));
     }
     {   // per-tile radius bounds, as unpack_slots maintains them from then on
@@ -914,7 +921,7 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_up
         HIP_TRY(hipMemsetAsync(c->meta, 0, sizeof(Meta), s));
         HIP_TRY(hipMemsetAsync(c->tile_rmax, 0, sizeof(unsigned) * (size_t)c->n_tiles, s));
         hipLaunchKernelGGL(ref_layout_pack_f32, dim3((numBodies + 255) / 256), dim3(256), 0, s, (const void*)d_bodyData,
-                           numBodies, (Rec<float>*)c->J, c->meta, c->tile_rmax);
+                           numBodies, (Rec<float>*)c->J, c->meta, c->tile_rmax, c->Jt);
         // aim the workspace at the caller's stream and at the velocities where they lie in the block
         const hipStream_t own_stream = c->stream;
         void* const own_vel = c->Vown;

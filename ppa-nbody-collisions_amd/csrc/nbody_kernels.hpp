@@ -675,13 +675,11 @@ constexpr int kRingDeadSeq = 0x40000000;                   // sequence number of
 // instructions do not use it).
 // 4 bytes per active lane: lane l's dword lands at lds_base + 4 * l.  The SOURCE address is per lane, so a strided gather
 // from the {x, y, m, r} records turns one component of 64 bodies into 64 consecutive LDS words.
-// The instruction's immediate offset is added to the global address AND to the LDS address: component c of the records
-// (kImm = 4 c) therefore needs M0 = (where the component array starts) - kImm, and all four components share ONE base
-// pointer (scalar registers are scarce in the ring kernel: every pair spilled to a VGPR lane costs v_readlanes per turn).
-template <int kImm>
+// (The instruction's immediate offset applies to the global AND the LDS address; offsets of 4 ... 12 bytes cost nothing,
+// 512 ... 1536 made these loads slow - +28 % kernel time -, so none is used.)
 __device__ __forceinline__ void load_to_lds_b32(const void* base, unsigned byte_offset, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%3"
-                 ::"s"(lds_dst - (unsigned)kImm), "v"(byte_offset), "s"(base), "n"(kImm) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
+                 ::"s"(lds_dst), "v"(byte_offset), "s"(base) : "memory");
 }
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
 
@@ -689,7 +687,8 @@ template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings>
 __global__ __launch_bounds__(kRings * kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
                      Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
-                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr, const float* __restrict__ tile_rmax) {
+                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr, const float* __restrict__ tile_rmax,
+                     const float* __restrict__ Jt) {
     typedef float T;
     typedef Pair<float>::type V2;
     static_assert(kTile % kT == 0 && kT % 8 == 0 && kT <= kWave, "turn length");
@@ -798,19 +797,31 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     const int nwin = lit ? (kWave + kT - 1) : kT;          // entries of the window that are used
     const unsigned e0 = (unsigned)(wbase0 + (w % kTurnsPerTile) * kT + l) & (kTile - 1);
     const unsigned e1 = e0 ^ kWave;                        // the entry 64 further on
-    auto window_offset = [&](long long st, unsigned e) -> unsigned {   // byte offset of the body's record in J
+    auto window_offset = [&](long long st, unsigned e) -> unsigned {   // byte offset of the body's x in the tiled copy Jt
         const unsigned src = (unsigned)st + e;
         const unsigned wrapped = src - (unsigned)N;        // huge when src < N
-        return (src < wrapped ? src : wrapped) * (unsigned)sizeof(Rec<T>);
+        const unsigned idx = src < wrapped ? src : wrapped;
+        return ((idx / kTile) * (4u * kTile) + (idx % kTile)) * (unsigned)sizeof(T);
     };
     // Loaded from the replica STRAIGHT INTO LDS, one component of 64 bodies per instruction (lane l's word lands at
     // base + 4 l; the per-lane source address does the transposition): the prefetch holds no registers and stays in
     // flight for a whole turn.  The radii are only fetched when some radius of the replica is not +0 (Meta::summary).
     auto issue_entries = [&](unsigned byte_offset, unsigned base, unsigned comp_bytes) {
-        load_to_lds_b32<0>(J, byte_offset, base);
-        load_to_lds_b32<4>(J, byte_offset, base + comp_bytes);
-        load_to_lds_b32<8>(J, byte_offset, base + 2 * comp_bytes);
-        if (any_radius) load_to_lds_b32<12>(J, byte_offset, base + 3 * comp_bytes);
+        // Source: Jt, the replica once more, tile by tile component-major (x[128] y[128] m[128] r[128] per aligned
+        // 128-body tile, written next to J by unpack_slots): a wave's 64 entries of one component are 256 contiguous
+        // bytes - two or three cache lines per instruction where the 16-byte records took eight or nine -, and the
+        // radius lines are never touched while every radius is +0: 3 of the 4 MiB, which an XCD's 4 MiB L2 keeps from one
+        // round of workgroups to the next (fabric-side reads halved, profiles/r02_traffic_pmc.json).
+        // The planes of a tile are 512 bytes apart.  Their base pointers are formed HERE, from an offset hipcc cannot see
+        // through: hoisted out of the turn loop they are three more scalar register pairs the kernel does not have
+        // (spilled pairs cost v_readlanes per turn).
+        unsigned long long plane = kTile * sizeof(T);
+        asm volatile("" : "+s"(plane));
+        const char* const src = (const char*)Jt;
+        load_to_lds_b32(src, byte_offset, base);
+        load_to_lds_b32(src + plane, byte_offset, base + comp_bytes);
+        load_to_lds_b32(src + 2 * plane, byte_offset, base + 2 * comp_bytes);
+        if (any_radius) load_to_lds_b32(src + 3 * plane, byte_offset, base + 3 * comp_bytes);
     };
     auto issue_window = [&](long long st, int buf) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0][0]));
@@ -1179,6 +1190,17 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
 // Stable compaction of the own range on `mass != 0` (src/nbody.cu:488-510), two small kernels.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kCompactBlock = 1024;
+// The tiled copy of the fp32 replica (the ring kernel's window source): body i of aligned tile i / 128 at x[i % 128],
+// y[...], m[...], r[...] of that tile's 2 KiB.
+template <typename T>
+__device__ __forceinline__ void store_tiled(float* __restrict__ Jt, int i, const Rec<T>& r) {
+    float* t = Jt + (size_t)(i / kTile) * (4 * kTile) + (i % kTile);
+    t[0] = (float)r.x; t[kTile] = (float)r.y; t[2 * kTile] = (float)r.m; t[3 * kTile] = (float)r.r;
+}
+__global__ __launch_bounds__(256) void records_to_tiles_f32(const Rec<float>* __restrict__ J, int n, float* __restrict__ Jt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) store_tiled(Jt, i, J[i]);
+}
 
 template <typename T>
 __global__ __launch_bounds__(kCompactBlock) void compact_count(const Rec<T>* __restrict__ S_J,
@@ -1260,7 +1282,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restrict__ gather, size_t slot_bytes,
                                                     int cap_own, int world, int rank, Rec<T>* __restrict__ J,
                                                     Vec2<T>* __restrict__ Vown, Meta* __restrict__ meta,
-                                                    unsigned* __restrict__ tile_rmax) {
+                                                    unsigned* __restrict__ tile_rmax, float* __restrict__ Jt) {
     const int g = blockIdx.y;
     int off = 0, total = 0;
     for (int h = 0; h < world; ++h) {
@@ -1281,6 +1303,7 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         const Rec<T> r = recs[q];
         const int i = off + q;                             // index of this body in step t+1
         J[i] = r;
+        if (Jt != nullptr) store_tiled(Jt, i, r);          // fp32 contexts
         if (i >= lo && i < lo + cnt) Vown[i - lo] = vels[q];
         const bool bounded = abs_(r.x) < FastDomain<T>::coord && abs_(r.y) < FastDomain<T>::coord;
         bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
@@ -1384,7 +1407,8 @@ __global__ __launch_bounds__(kTile) void ref_layout_forces_f32(void* bodyData, f
 // velocities where they lie in the block, and its staged output is written back in the reference's form:
 // velocities in place, updatedMasses / updatedRadii (src/nbody.cu:245-246,264).  meta and tile_rmax are zeroed before.
 __global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData, int N, Rec<float>* __restrict__ J,
-                                                           Meta* __restrict__ meta, unsigned* __restrict__ tile_rmax) {
+                                                           Meta* __restrict__ meta, unsigned* __restrict__ tile_rmax,
+                                                           float* __restrict__ Jt) {
     const Vec2<float>* P = reinterpret_cast<const Vec2<float>*>(bodyData);    // :147-150
     const float* M = reinterpret_cast<const float*>(P + 2 * (size_t)N);
     const float* R = M + N;
@@ -1395,6 +1419,7 @@ __global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData,
         const Vec2<float> pi = P[i];
         const Rec<float> r{pi.x, pi.y, M[i], R[i]};
         J[i] = r;
+        store_tiled(Jt, i, r);
         const bool bounded = abs_(r.x) < FastDomain<float>::coord && abs_(r.y) < FastDomain<float>::coord;
         bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
         const float ar = abs_(r.r);
