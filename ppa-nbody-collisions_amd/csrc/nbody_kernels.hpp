@@ -806,7 +806,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     // Loaded from the replica STRAIGHT INTO LDS, one component of 64 bodies per instruction (lane l's word lands at
     // base + 4 l; the per-lane source address does the transposition): the prefetch holds no registers and stays in
     // flight for a whole turn.  The radii are only fetched when some radius of the replica is not +0 (Meta::summary).
-    auto issue_entries = [&](unsigned byte_offset, unsigned base, unsigned comp_bytes) {
+    auto issue_entries = [&](unsigned tile_byte, unsigned byte_offset, unsigned base, unsigned comp_bytes) {
         // Source: Jt, the replica once more, tile by tile component-major (x[128] y[128] m[128] r[128] per aligned
         // 128-body tile, written next to J by unpack_slots): a wave's 64 entries of one component are 256 contiguous
         // bytes - two or three cache lines per instruction where the 16-byte records took eight or nine -, and the
@@ -817,7 +817,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         // (spilled pairs cost v_readlanes per turn).
         unsigned long long plane = kTile * sizeof(T);
         asm volatile("" : "+s"(plane));
-        const char* const src = (const char*)Jt;
+        const char* const src = (const char*)Jt + tile_byte;
         load_to_lds_b32(src, byte_offset, base);
         load_to_lds_b32(src + plane, byte_offset, base + comp_bytes);
         load_to_lds_b32(src + 2 * plane, byte_offset, base + 2 * comp_bytes);
@@ -825,8 +825,16 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     };
     auto issue_window = [&](long long st, int buf) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0][0]));
-        if (l < nwin) issue_entries(window_offset(st, e0), base, kWin * (unsigned)sizeof(T));
-        if (l + kWave < nwin) issue_entries(window_offset(st, e1), base + kWave * (unsigned)sizeof(T), kWin * (unsigned)sizeof(T));
+        if (((unsigned)st & (kTile - 1)) == 0u && st + kTile <= N) {
+            // the common case - the window's tile is an aligned tile of Jt -: the tile goes into the scalar base address,
+            // the lanes' offsets are the two per-lane constants, no vector arithmetic at all
+            const unsigned tile_byte = ((unsigned)st / kTile) * (4u * kTile * (unsigned)sizeof(T));
+            if (l < nwin) issue_entries(tile_byte, e0 * (unsigned)sizeof(T), base, kWin * (unsigned)sizeof(T));
+            if (l + kWave < nwin) issue_entries(tile_byte, e1 * (unsigned)sizeof(T), base + kWave * (unsigned)sizeof(T), kWin * (unsigned)sizeof(T));
+        } else {
+            if (l < nwin) issue_entries(0u, window_offset(st, e0), base, kWin * (unsigned)sizeof(T));
+            if (l + kWave < nwin) issue_entries(0u, window_offset(st, e1), base + kWave * (unsigned)sizeof(T), kWin * (unsigned)sizeof(T));
+        }
     };
     // A truncated tile: its L <= 128 entries in order, component-major x[128] y[128] m[128] r[128] across BOTH window
     // buffers (2 * 4 * kWin >= 4 * 128 words), so it can only be issued when the wave is done with its current window:
@@ -835,8 +843,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     float* const whole = &win[w][0][0][0];
     auto issue_truncated = [&](long long st, int L) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(whole));
-        if (l < L) issue_entries(window_offset(st, (unsigned)l), base, kTile * (unsigned)sizeof(T));
-        if (l + kWave < L) issue_entries(window_offset(st, (unsigned)(l + kWave)), base + kWave * (unsigned)sizeof(T), kTile * (unsigned)sizeof(T));
+        if (l < L) issue_entries(0u, window_offset(st, (unsigned)l), base, kTile * (unsigned)sizeof(T));
+        if (l + kWave < L) issue_entries(0u, window_offset(st, (unsigned)(l + kWave)), base + kWave * (unsigned)sizeof(T), kTile * (unsigned)sizeof(T));
     };
     // one entry of a window / of the whole truncated tile, as a record (general code only)
     auto window_record = [&](const float* comp0, int stride, int idx) -> Rec<T> {
