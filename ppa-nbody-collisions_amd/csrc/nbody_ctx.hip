@@ -89,6 +89,10 @@ constexpr int kNcclInt8 = 0;   // ncclInt8 / ncclChar
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
+constexpr size_t kCountersOffset = 64;                                    // Meta is 32 bytes
+constexpr size_t kMetaBlockBytes = kCountersOffset + sizeof(Counters);
+static_assert(sizeof(Meta) <= kCountersOffset, "Meta fits before the counters");
+
 struct nbody_ctx {
     nbody_ctx_desc desc{};
     size_t real_bytes = 4;      // sizeof(T)
@@ -366,8 +370,7 @@ int commit_phase(nbody_ctx* c) {
     c->steps += 1;
     // Counts only shrink, so a count read back late is still an upper bound: copy Meta to pinned memory
     // without waiting and let later launches size their grids / pick their kernel from whatever has landed.
-    HIP_TRY(hipMemcpyAsync(c->h_meta_async, c->meta, sizeof(Meta), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->h_counters_async, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_meta_async, c->meta, kMetaBlockBytes, hipMemcpyDeviceToHost, c->stream));   // Meta and Counters
     return NBODY_OK;
 }
 
@@ -380,12 +383,11 @@ void free_all(nbody_ctx* c) {
     hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
     if (c->gather && c->gather != c->slot) hipFree(c->gather);
     hipFree(c->slot);
-    hipFree(c->blk_counts); hipFree(c->tile_rmax); hipFree(c->Jt); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->counters); hipFree(c->events); hipFree(c->d_img);
+    hipFree(c->blk_counts); hipFree(c->tile_rmax); hipFree(c->Jt); hipFree(c->meta); hipFree(c->meta_all); hipFree(c->events); hipFree(c->d_img);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->h_meta) hipHostFree(c->h_meta);
     if (c->h_meta_async) hipHostFree(c->h_meta_async);
     if (c->h_counters) hipHostFree(c->h_counters);
-    if (c->h_counters_async) hipHostFree(c->h_counters_async);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -471,9 +473,10 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
         CTX_TRY(hipMalloc((void**)&c->Jt, sizeof(float) * 4 * kTile * (size_t)c->n_tiles));
         CTX_TRY(hipMemset(c->Jt, 0, sizeof(float) * 4 * kTile * (size_t)c->n_tiles));
     }
-    CTX_TRY(hipMalloc((void**)&c->meta, sizeof(Meta)));
+    // Meta and Counters share one device block (and one pinned host block): the per-step look at them is ONE copy
+    CTX_TRY(hipMalloc((void**)&c->meta, kMetaBlockBytes));
+    c->counters = reinterpret_cast<Counters*>(reinterpret_cast<unsigned char*>(c->meta) + kCountersOffset);
     if (use_comm) CTX_TRY(hipMalloc((void**)&c->meta_all, sizeof(Meta) * (size_t)d->world));
-    CTX_TRY(hipMalloc((void**)&c->counters, sizeof(Counters)));
     CTX_TRY(hipMalloc((void**)&c->events, sizeof(Event) * (size_t)c->ev_cap));
     // on the context's own stream and waited for: hipMemset() on device memory runs on the NULL stream and may
     // return before the fill has executed; the context's stream is non-blocking, so a late fill could land
@@ -484,9 +487,9 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     c->h_stage_bytes = (size_t)c->cap * c->rec_bytes;
     CTX_TRY(hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
     CTX_TRY(hipHostMalloc((void**)&c->h_meta, sizeof(Meta), hipHostMallocDefault));
-    CTX_TRY(hipHostMalloc((void**)&c->h_meta_async, sizeof(Meta), hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc((void**)&c->h_meta_async, kMetaBlockBytes, hipHostMallocDefault));
+    c->h_counters_async = reinterpret_cast<Counters*>(reinterpret_cast<unsigned char*>(c->h_meta_async) + kCountersOffset);
     CTX_TRY(hipHostMalloc((void**)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
-    CTX_TRY(hipHostMalloc((void**)&c->h_counters_async, sizeof(Counters), hipHostMallocDefault));
     memset(c->h_counters, 0, sizeof(Counters));
     memset(c->h_counters_async, 0, sizeof(Counters));
 #undef CTX_TRY
