@@ -731,9 +731,9 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
     const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
     BodyAcc<T> a;
-    if (mine) {
-        const Rec<T> me = J[i];
-        a.xi = me.x; a.yi = me.y; a.mi = me.m; a.ri = me.r;
+    if (mine) {                                            // own start-of-step state, from the tile-planar copy like the windows
+        const float* me = Jt + (size_t)(i / kTile) * (4 * kTile) + (i % kTile);
+        a.xi = me[0]; a.yi = me[kTile]; a.mi = me[2 * kTile]; a.ri = me[3 * kTile];
     } else {
         a.xi = a.yi = a.mi = a.ri = 0;
     }
