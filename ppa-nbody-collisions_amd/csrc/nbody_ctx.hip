@@ -195,8 +195,9 @@ int own_upper_of(const nbody_ctx* c, int n) { return nbody_own_upper_of(n, c->de
 int device_failure(nbody_ctx* c, unsigned long long errors) {
     if (errors != 0) c->device_failed = true;
     if (!c->device_failed) return NBODY_OK;
-    return nbody_fail(NBODY_ERR_HIP, "device reported %llu in-kernel hand-off time-out(s): the state is poisoned (NaN), "
-                                     "upload again", errors);
+    return nbody_fail(NBODY_ERR_HIP, "device reported %llu in-kernel hand-off time-out(s) (the state is poisoned: NaN) and "
+                                     "%llu failed index check(s) (the access was skipped): upload again",
+                      errors % kIndexError, errors / kIndexError);
 }
 
 // Synchronises the stream and refreshes the host copies of Meta and Counters; fails if the device reported a failure.
@@ -213,18 +214,26 @@ int read_meta(nbody_ctx* c) {
 //                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body, 128-thread workgroups |
 //                 31,32 v3 K = 1 with 256-thread workgroups, registers sized for 4 / 2 waves per SIMD |
 //                 50,52,54 ring of waves with 2x8, 4x4, 1x8 (rings x waves) per workgroup; 53,58 its tuning forms
+// Where a force launch goes: the context's own stream and velocities, or - the reference-shaped launch through the
+// workspace context - the caller's stream and the velocities where they lie in the caller's block.
+struct LaunchTarget {
+    hipStream_t stream;
+    const void* vown;
+};
+LaunchTarget own_target(const nbody_ctx* c) { return LaunchTarget{c->stream, c->Vown}; }
+
 template <typename T>
-void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log);
+void launch_forces(nbody_ctx* c, const StepParams<T>& p, int nblocks, bool log, LaunchTarget to);
 
 #define NB_FORCES_ARGS(T)                                                                                 \
-    (const Rec<T>*)c->J, (const Vec2<T>*)c->Vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V, (const Meta*)c->meta, p, \
+    (const Rec<T>*)c->J, (const Vec2<T>*)to.vown, (Rec<T>*)c->S_J, (Vec2<T>*)c->S_V, (const Meta*)c->meta, p, \
         c->events, c->ev_cap, c->counters
 
 template <>
-void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblocks, bool log) {
+void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblocks, bool log, LaunchTarget to) {
     if (c->desc.kernel_variant == 1) {                     // general kernel: compiler IEEE sqrt / divide per pair
-        if (log) hipLaunchKernelGGL((forces_v1<double, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
-        else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(double));
+        if (log) hipLaunchKernelGGL((forces_v1<double, true>), dim3(nblocks), dim3(kTile), 0, to.stream, NB_FORCES_ARGS(double));
+        else hipLaunchKernelGGL((forces_v1<double, false>), dim3(nblocks), dim3(kTile), 0, to.stream, NB_FORCES_ARGS(double));
         return;
     }
     const int grid = (nblocks + 1) / 2;                    // two 128-lane groups per workgroup
@@ -233,51 +242,55 @@ void launch_forces<double>(nbody_ctx* c, const StepParams<double>& p, int nblock
     StepParams<double> pr = p;
     pr.rotate_priority = grid <= 3 * c->num_cus;
 #define NB_FORCES_ARGS_PR                                                                                  \
-    (const Rec<double>*)c->J, (const Vec2<double>*)c->Vown, (Rec<double>*)c->S_J, (Vec2<double>*)c->S_V,    \
+    (const Rec<double>*)c->J, (const Vec2<double>*)to.vown, (Rec<double>*)c->S_J, (Vec2<double>*)c->S_V,    \
         (const Meta*)c->meta, pr, c->events, c->ev_cap, c->counters
-    if (log) hipLaunchKernelGGL((forces_v3w_f64<true>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS_PR);
-    else hipLaunchKernelGGL((forces_v3w_f64<false>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS_PR);
+    if (log) hipLaunchKernelGGL((forces_v3w_f64<true>), dim3(grid), dim3(2 * kTile), 0, to.stream, NB_FORCES_ARGS_PR);
+    else hipLaunchKernelGGL((forces_v3w_f64<false>), dim3(grid), dim3(2 * kTile), 0, to.stream, NB_FORCES_ARGS_PR);
 #undef NB_FORCES_ARGS_PR
 }
 
 template <int K>
-void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+void launch_v3(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log, LaunchTarget to) {
     const int grid = nblocks * K;
-    if (log) hipLaunchKernelGGL((forces_v3_f32<K, true>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+    if (log) hipLaunchKernelGGL((forces_v3_f32<K, true>), dim3(grid), dim3(kTile), 0, to.stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_v3_f32<K, false>), dim3(grid), dim3(kTile), 0, to.stream, NB_FORCES_ARGS(float));
 }
 
 template <int K, int kOcc>
-void launch_v3w(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+void launch_v3w(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log, LaunchTarget to) {
     const int grid = (nblocks * K + 1) / 2;                // two 128-lane groups per workgroup
-    if (log) hipLaunchKernelGGL((forces_v3w_f32<K, true, kOcc>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(float));
-    else hipLaunchKernelGGL((forces_v3w_f32<K, false, kOcc>), dim3(grid), dim3(2 * kTile), 0, c->stream, NB_FORCES_ARGS(float));
+    if (log) hipLaunchKernelGGL((forces_v3w_f32<K, true, kOcc>), dim3(grid), dim3(2 * kTile), 0, to.stream, NB_FORCES_ARGS(float));
+    else hipLaunchKernelGGL((forces_v3w_f32<K, false, kOcc>), dim3(grid), dim3(2 * kTile), 0, to.stream, NB_FORCES_ARGS(float));
 }
 
 template <int kW, int kT, int kSleep, bool kProbe, int kRings>
-void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log, LaunchTarget to) {
     const int grid = (nblocks * 2 + kRings - 1) / kRings;  // a workgroup serves kRings rings of 64 bodies, two per reference block
-    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax, (const float*)c->Jt);
-    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, c->stream, NB_FORCES_ARGS(float), (const float*)c->tile_rmax, (const float*)c->Jt);
+    RingArgs a;
+    a.Vown = (const Vec2<float>*)to.vown; a.S_J = (Rec<float>*)c->S_J; a.S_V = (Vec2<float>*)c->S_V;
+    a.meta = c->meta; a.p = p; a.ev = c->events; a.ev_cap = c->ev_cap; a.ctr = c->counters;
+    a.tile_rmax = (const float*)c->tile_rmax; a.Jt = c->Jt; a.cap_own = c->cap_own; a.n_tiles = c->n_tiles;
+    if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, to.stream, a);
+    else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, to.stream, a);
 }
 template <>
-void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log) {
+void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log, LaunchTarget to) {
     switch (c->desc.kernel_variant) {
         case 1:
-            if (log) hipLaunchKernelGGL((forces_v1<float, true>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
-            else hipLaunchKernelGGL((forces_v1<float, false>), dim3(nblocks), dim3(kTile), 0, c->stream, NB_FORCES_ARGS(float));
+            if (log) hipLaunchKernelGGL((forces_v1<float, true>), dim3(nblocks), dim3(kTile), 0, to.stream, NB_FORCES_ARGS(float));
+            else hipLaunchKernelGGL((forces_v1<float, false>), dim3(nblocks), dim3(kTile), 0, to.stream, NB_FORCES_ARGS(float));
             return;
-        case 11: launch_v3<1>(c, p, nblocks, log); return;
-        case 12: launch_v3<2>(c, p, nblocks, log); return;
-        case 14: launch_v3<4>(c, p, nblocks, log); return;
-        case 18: launch_v3<8>(c, p, nblocks, log); return;
-        case 31: launch_v3w<1, 4>(c, p, nblocks, log); return;
-        case 32: launch_v3w<1, 2>(c, p, nblocks, log); return;
-        case 50: launch_ring<8, 32, 8, false, 2>(c, p, nblocks, log); return;   // 2 rings of 8 waves per workgroup
-        case 52: launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log); return;   // 4 rings of 4 waves per workgroup
-        case 54: launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log); return;   // one ring of 8 waves per workgroup
-        case 53: launch_ring<8, 16, 8, false, 2>(c, p, nblocks, log); return;   // tuning: turns of 16 positions
-        case 58: launch_ring<8, 32, 8, true, 2>(c, p, nblocks, log); return;    // tuning: in-kernel phase stamps
+        case 11: launch_v3<1>(c, p, nblocks, log, to); return;
+        case 12: launch_v3<2>(c, p, nblocks, log, to); return;
+        case 14: launch_v3<4>(c, p, nblocks, log, to); return;
+        case 18: launch_v3<8>(c, p, nblocks, log, to); return;
+        case 31: launch_v3w<1, 4>(c, p, nblocks, log, to); return;
+        case 32: launch_v3w<1, 2>(c, p, nblocks, log, to); return;
+        case 50: launch_ring<8, 32, 8, false, 2>(c, p, nblocks, log, to); return;   // 2 rings of 8 waves per workgroup
+        case 52: launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log, to); return;   // 4 rings of 4 waves per workgroup
+        case 54: launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log, to); return;   // one ring of 8 waves per workgroup
+        case 53: launch_ring<8, 16, 8, false, 2>(c, p, nblocks, log, to); return;   // tuning: turns of 16 positions
+        case 58: launch_ring<8, 32, 8, true, 2>(c, p, nblocks, log, to); return;    // tuning: in-kernel phase stamps
         default: break;
     }
     // default: chosen by how many bodies this rank owns, i.e. how many ordered chains there are to fill the chip with
@@ -291,9 +304,9 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
     // Poll interval of the hand-off wait: s_sleep 8 (512 cycles) where the launch is bound by evaluation - a poll takes
     // issue slots from the waves that evaluate: -0.5 ... -1 % against s_sleep 2 -, s_sleep 2 for the small launches, which
     // are bound by the chain (N = 16384: 0.185 ms; with s_sleep 8: 0.218).
-    if (c->own_upper >= 49152) launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log);
-    else if (c->own_upper >= 24576) launch_ring<8, 32, 8, false, 2>(c, p, nblocks, log);
-    else launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log);
+    if (c->own_upper >= 49152) launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log, to);
+    else if (c->own_upper >= 24576) launch_ring<8, 32, 8, false, 2>(c, p, nblocks, log, to);
+    else launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log, to);
 }
 
 template <typename T>
@@ -305,7 +318,7 @@ int launch_force_kernel(nbody_ctx* c, const StepParams<T>& p, int nblocks) {
         HIP_TRY(hipEventRecord(e0, c->stream));
     }
     const bool log = (c->desc.flags & NBODY_FLAG_RECORD_EVENTS) != 0;
-    launch_forces<T>(c, p, nblocks, log);
+    launch_forces<T>(c, p, nblocks, log, own_target(c));
     HIP_TRY(hipGetLastError());
     if (c->timing) {
         HIP_TRY(hipEventRecord(e1, c->stream));
@@ -897,8 +910,16 @@ int ref_launch_workspace(int n, nbody_ctx** out) {
 }  // namespace
 
 int nbody_launch_workspace_release(void) {
-    if (g_ref_ws) { nbody_ctx_destroy(g_ref_ws); g_ref_ws = nullptr; g_ref_ws_device = -1; }
-    return NBODY_OK;
+    int rc = NBODY_OK;
+    if (g_ref_ws) {
+        hipSetDevice(g_ref_ws->desc.device);
+        hipDeviceSynchronize();                            // launches through the workspace ran on the callers' streams
+        rc = device_failure(g_ref_ws, *(volatile unsigned long long*)&g_ref_ws->h_counters_async->errors);
+        nbody_ctx_destroy(g_ref_ws);
+        g_ref_ws = nullptr;
+        g_ref_ws_device = -1;
+    }
+    return rc;
 }
 
 int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_updR, int numBodies,
@@ -921,24 +942,24 @@ int nbody_launch_compute_forces_f32(void* d_bodyData, float* d_updM, float* d_up
         int rc = ref_launch_workspace(numBodies, &c);
         if (rc != NBODY_OK) return rc;
         hipStream_t s = (hipStream_t)stream;
+        // CUDA_SYNC_CHECK's convention (src/nbody.cu:20-33): a device-side failure of an EARLIER launch through the
+        // workspace (a hand-off time-out poisons the caller's block with NaN) is reported by the next call that looks
+        rc = device_failure(c, *(volatile unsigned long long*)&c->h_counters_async->errors);
+        if (rc != NBODY_OK) return rc;
         HIP_TRY(hipMemsetAsync(c->meta, 0, sizeof(Meta), s));
         HIP_TRY(hipMemsetAsync(c->tile_rmax, 0, sizeof(unsigned) * (size_t)c->n_tiles, s));
         hipLaunchKernelGGL(ref_layout_pack_f32, dim3((numBodies + 255) / 256), dim3(256), 0, s, (const void*)d_bodyData,
                            numBodies, (Rec<float>*)c->J, c->meta, c->tile_rmax, c->Jt);
-        // aim the workspace at the caller's stream and at the velocities where they lie in the block
-        const hipStream_t own_stream = c->stream;
-        void* const own_vel = c->Vown;
-        c->stream = s;
-        c->Vown = (float*)d_bodyData + 2 * (size_t)numBodies;
-        c->own_upper = c->n_upper = numBodies;
+        // the caller's stream, and the velocities where they lie in the caller's block
+        c->own_upper = c->n_upper = numBodies;             // (kernel choice by size, as in a context of this many bodies)
         StepParams<float> pr = p;
         pr.spin_limit = c->spin_limit;
-        launch_forces<float>(c, pr, numBodies / kTile > 0 ? numBodies / kTile : 1, false);
-        c->stream = own_stream;
-        c->Vown = own_vel;
+        launch_forces<float>(c, pr, numBodies / kTile > 0 ? numBodies / kTile : 1, false,
+                             LaunchTarget{s, (const float*)d_bodyData + 2 * (size_t)numBodies});
         const int n_active = numBodies < kTile ? numBodies : (numBodies / kTile) * kTile;
         hipLaunchKernelGGL(ref_layout_finish_f32, dim3((n_active + 255) / 256), dim3(256), 0, s, d_bodyData, d_updM, d_updR,
                            numBodies, n_active, (const Rec<float>*)c->S_J, (const Vec2<float>*)c->S_V);
+        HIP_TRY(hipMemcpyAsync(c->h_counters_async, c->counters, sizeof(Counters), hipMemcpyDeviceToHost, s));
     } else if (numBlocks == nbody_num_blocks(numBodies) && !(force_general && force_general[0] == '1')) {
         // NBODY_REF_LAUNCH_ONE_LANE=1: the one-lane-per-body kernel directly on the block layout, no workspace (round 1's
         // form of this launch; kept as a second implementation the tests compare)

@@ -63,7 +63,8 @@ struct Event { int32_t step, i, j, kind; };
 struct Counters {
     unsigned long long pairs;     // ordered pairs evaluated (this rank)
     unsigned long long events;    // events logged (may exceed capacity: overflow is counted, not stored)
-    unsigned long long errors;    // device-side failures (an in-kernel hand-off wait timed out)
+    unsigned long long errors;    // device-side failures: in-kernel hand-off waits that timed out (low half) and index
+                                  // checks that failed (kIndexError each: high half); either makes the host fail loudly
     unsigned long long probe[8];  // tuning builds of the ring kernel: cycle totals per phase (kProbe)
 };
 
@@ -665,10 +666,16 @@ __device__ __forceinline__ double dpp_row_shl(double v) {   // K > 1 is fp32 onl
 typedef __attribute__((address_space(3))) void* LdsPtr;
 typedef int Int4 __attribute__((ext_vector_type(4)));
 typedef float Float2 __attribute__((ext_vector_type(2)));
+typedef float Float4 __attribute__((ext_vector_type(4)));
 typedef volatile __attribute__((address_space(3))) Int4* LdsInt4Ptr;
-typedef volatile __attribute__((address_space(3))) Float2* LdsFloat2Ptr;
+typedef volatile __attribute__((address_space(3))) Float4* LdsFloat4Ptr;
 
 constexpr int kRingDeadSeq = 0x40000000;                   // sequence number of a poisoned chain
+// Index checks: the role of CUDA_SYNC_CHECK (src/nbody.cu:20-33) for the addresses the ring kernel forms itself.  The
+// staging store of the epilogue is checked in every build; the event-logging builds (kLog - the builds of round 2's
+// unexplained fault) also check the source range of every window gather and the radius-bound lookups.  A
+// failed check SKIPS the access and adds kIndexError to Counters::errors: the host then fails like after a time-out.
+constexpr unsigned long long kIndexError = 1ull << 32;
 
 // Global memory straight into LDS (gfx950 LDS-DMA).  Inline assembly on purpose: hipcc tracks the builtin form as a writer
 // of all LDS and waits vmcnt(0) before the next LDS read.  M0 is written by nothing else in these kernels (gfx9 DS
@@ -677,19 +684,58 @@ constexpr int kRingDeadSeq = 0x40000000;                   // sequence number of
 // from the {x, y, m, r} records turns one component of 64 bodies into 64 consecutive LDS words.
 // (The instruction's immediate offset applies to the global AND the LDS address; offsets of 4 ... 12 bytes cost nothing,
 // 512 ... 1536 made these loads slow - +28 % kernel time -, so none is used.)
+// M0 is declared clobbered although hipcc treats it as reserved (it never keeps a value of its own there: the ISA of
+// every build of these kernels is identical with and without the clobber) and says so with -Winline-asm.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void load_to_lds_b32(const void* base, unsigned byte_offset, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2"
-                 ::"s"(lds_dst), "v"(byte_offset), "s"(base) : "memory");
+                 ::"s"(lds_dst), "v"(byte_offset), "s"(base) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ unsigned lds_offset_of(const void* p) { return (unsigned)(unsigned long long)(LdsPtr)p; }
+
+// The kernel's arguments travel as ONE struct.  What the turn loop needs (meta, Jt, tile_rmax, two flags of p) is read
+// from it the usual way; everything else - the staging arrays and step parameters of the epilogue, the event log of the
+// rare path - is loaded from the kernarg segment WHERE IT IS USED (ring_late_arg): hipcc loads every kernel argument
+// it can see at the kernel's entry and keeps it in scalar registers to the end, and this kernel has none to spare
+// (spilled scalars cost v_readlanes per turn, a spilled vector register a scratch access inside the loop).
+struct RingArgs {
+    const Vec2<float>* Vown;
+    Rec<float>* S_J;
+    Vec2<float>* S_V;
+    const Meta* meta;
+    StepParams<float> p;
+    Event* ev;
+    int ev_cap;
+    Counters* ctr;
+    const float* tile_rmax;
+    const float* Jt;
+    int cap_own;                 // entries of Vown / S_J / S_V
+    int n_tiles;                 // entries of tile_rmax, 2 KiB tiles of Jt
+};
+template <typename A>
+__device__ __forceinline__ A ring_late_arg(unsigned byte_offset) {
+#if defined(__HIP_DEVICE_COMPILE__)                        // (the host pass of hipcc only needs the declaration)
+    typedef const __attribute__((address_space(4))) char* KernargBytes;
+    const KernargBytes ka = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(byte_offset));                  // an offset hipcc cannot see through: the load stays here
+    return *(const __attribute__((address_space(4))) A*)(ka + byte_offset);   // a scalar load (s_load_*)
+#else
+    (void)byte_offset;
+    return A{};
+#endif
+}
+#define NB_RING_LATE(field) \
+    ring_late_arg<decltype(((const RingArgs*)nullptr)->field)>((unsigned)__builtin_offsetof(RingArgs, field))
 
 template <bool kLog, int kW, int kT, int kSleep, bool kProbe, int kRings>
 __global__ __launch_bounds__(kRings * kW * kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __restrict__ Vown,
-                     Rec<float>* __restrict__ S_J, Vec2<float>* __restrict__ S_V, const Meta* __restrict__ meta,
-                     StepParams<float> p, Event* ev, int ev_cap, Counters* ctr, const float* __restrict__ tile_rmax,
-                     const float* __restrict__ Jt) {
+void forces_ring_f32(const RingArgs args) {
     typedef float T;
+    const Meta* __restrict__ const meta = args.meta;
+    const float* __restrict__ const tile_rmax = args.tile_rmax;
+    const float* __restrict__ const Jt = args.Jt;
     typedef Pair<float>::type V2;
     static_assert(kTile % kT == 0 && kT % 8 == 0 && kT <= kWave, "turn length");
     constexpr int kTurnsPerTile = kTile / kT;
@@ -703,8 +749,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     // were packed per position: one more instruction per pair, plus moves that paired the mass with its operand).
     __shared__ float win_all[kRings][kW][2][4][kWin];
     __shared__ Int4 hand_all[kRings][kWave];               // {fx, fy, seq, flags = version << 1 | deleted} per lane
-    __shared__ Float2 hand_m_all[kRings][kWave];           // {mnew, rnew}, rewritten only when they change
-    const int N = meta->n, lo = meta->lo, cnt = meta->cnt, step = meta->step;
+    __shared__ Float4 hand_m_all[kRings][kWave];           // {mnew, rnew, mi, -}: rewritten only when mnew / rnew change
+    const int N = meta->n, lo = meta->lo, cnt = meta->cnt;
     const bool all_bounded = (meta->summary & kSummaryUnbounded) == 0, any_radius = (meta->summary & kSummaryRadius) != 0;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -720,34 +766,49 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     const long long blk0 = (long long)b * kTile;
     float(&win)[kW][2][4][kWin] = win_all[ring];
     Int4(&hand)[kWave] = hand_all[ring];
-    Float2(&hand_m)[kWave] = hand_m_all[ring];
+    Float4(&hand_m)[kWave] = hand_m_all[ring];
     const int nb = N < kTile ? 1 : N / kTile;              // src/nbody.cu:473
-    const bool lit = p.literal != 0;
+    const bool lit = args.p.literal != 0;
     const int ntiles = lit ? nb : (N + kTile - 1) / kTile;
     const int nturns = ntiles * kTurnsPerTile;
 
-    const long long i64 = blk0 + t;
-    const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
-    const bool mine = i64 >= lo && i64 < (long long)lo + cnt;
-    const bool active = mine && i64 < N && (!lit || i64 < (long long)nb * kTile);
-    BodyAcc<T> a;
-    if (mine) {                                            // own start-of-step state, from the tile-planar copy like the windows
-        const float* me = Jt + (size_t)(i / kTile) * (4 * kTile) + (i % kTile);
-        a.xi = me[0]; a.yi = me[kTile]; a.mi = me[2 * kTile]; a.ri = me[3 * kTile];
-    } else {
-        a.xi = a.yi = a.mi = a.ri = 0;
+    const bool mine = blk0 + t >= lo && blk0 + t < (long long)lo + cnt;
+    const bool active = mine && blk0 + t < N && (!lit || blk0 + t < (long long)nb * kTile);
+    // The lane's body index, formed where it is needed (rare path, epilogue) from a lane number hipcc cannot see through:
+    // kept across the turn loop it is two vector registers the evaluation cannot spare.
+    auto body_index64 = [&]() -> long long {
+        int lane = l;
+        asm volatile("" : "+v"(lane));
+        return blk0 + t0 + lane;
+    };
+    // What a lane keeps in REGISTERS across the turns is its position and radius only: every fast turn needs them.  The
+    // rest of its state lives in LDS between turns - the running sum and `deleted` in the hand-off record, {mnew, rnew, mi}
+    // in the rare record - and is picked up where it is needed: by the general code and by the epilogue.
+    T xi = 0, yi = 0, ri = 0;
+    {
+        T mi = 0;
+        if (mine) {                                        // own start-of-step state, from the tile-planar copy like the windows
+            const long long i64 = blk0 + t;
+            const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+            const float* me = Jt + (size_t)(i / kTile) * (4 * kTile) + (i % kTile);
+            xi = me[0]; yi = me[kTile]; mi = me[2 * kTile]; ri = me[3 * kTile];
+        }
+        // the loads are waited for HERE: left to hipcc, the wait for `ri` lands at its first use - inside the turn loop,
+        // behind the next window's prefetch, which it would then wait for in every turn
+        asm volatile("" : "+v"(xi), "+v"(yi), "+v"(mi), "+v"(ri));
+        if (w == 0) {
+            *(LdsInt4Ptr)&hand[l] = Int4{0, 0, 0, 0};
+            *(LdsFloat4Ptr)&hand_m[l] = Float4{mi, ri, mi, 0.0f};            // mnew = mi, rnew = ri (:174-175)
+        }
     }
-    a.fx = 0; a.fy = 0; a.mnew = a.mi; a.rnew = a.ri; a.deleted = 0;
-    int mver = 0;                                          // version of {mnew, rnew} this wave holds
-    const int spin_limit = __builtin_amdgcn_readfirstlane(p.spin_limit);   // (kept out of the poll loop's reach)
+    const int spin_limit = __builtin_amdgcn_readfirstlane(args.p.spin_limit);   // (kept out of the poll loop's reach)
     bool dead = false;
     int timeouts = 0;
-    const bool lane_ok = !active || ((abs_(a.xi) < kCoordBound) && (abs_(a.yi) < kCoordBound));
+    const bool lane_ok = !active || ((abs_(xi) < kCoordBound) && (abs_(yi) < kCoordBound));
     const bool wave_ok = __ballot(!lane_ok) == 0ull;
-    unsigned long long pairs = 0;
+    int pairs_rare = 0;                                    // pairs of this lane's turns that left the common path
     const LdsInt4Ptr hand_l = (LdsInt4Ptr)&hand[l];
-    const LdsFloat2Ptr hand_m_l = (LdsFloat2Ptr)&hand_m[l];
-    if (w == 0) *hand_l = Int4{0, 0, 0, 0};
+    const LdsFloat4Ptr hand_m_l = (LdsFloat4Ptr)&hand_m[l];
     __syncthreads();                                       // the only workgroup barrier: seq = 0 everywhere
     if (blk0 + t0 >= (long long)lo + cnt) return;          // a ring without own bodies (after the barrier)
     // Two rings share a CU's SIMDs (two per workgroup here, or two workgroups per CU), and the instruction arbiter
@@ -795,8 +856,12 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     // per-lane constants, the body index is that plus the tile's first body, wrapped at most once (st < N, e < 128 <= N).
     const int wbase0 = lit ? t0 : 0;                       // literal: lane l reads window[l + r]; clean: window[r]
     const int nwin = lit ? (kWave + kT - 1) : kT;          // entries of the window that are used
-    const unsigned e0 = (unsigned)(wbase0 + (w % kTurnsPerTile) * kT + l) & (kTile - 1);
-    const unsigned e1 = e0 ^ kWave;                        // the entry 64 further on
+    // (recomputed per window from the lane number - two instructions - instead of living in two registers)
+    auto first_entry = [&]() -> unsigned {
+        int lane = l;
+        asm volatile("" : "+v"(lane));
+        return (unsigned)(wbase0 + (w % kTurnsPerTile) * kT + lane) & (kTile - 1);
+    };
     auto window_offset = [&](long long st, unsigned e) -> unsigned {   // byte offset of the body's x in the tiled copy Jt
         const unsigned src = (unsigned)st + e;
         const unsigned wrapped = src - (unsigned)N;        // huge when src < N
@@ -817,6 +882,13 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         // (spilled pairs cost v_readlanes per turn).
         unsigned long long plane = kTile * sizeof(T);
         asm volatile("" : "+s"(plane));
+        if (kLog) {                                        // the four words this lane fetches lie inside Jt
+            const unsigned long long last = (unsigned long long)tile_byte + byte_offset + 3 * kTile * sizeof(T) + sizeof(T);
+            if (last > (unsigned long long)NB_RING_LATE(n_tiles) * (4 * kTile * sizeof(T))) {
+                atomicAdd(&NB_RING_LATE(ctr)->errors, kIndexError);
+                return;
+            }
+        }
         const char* const src = (const char*)Jt + tile_byte;
         load_to_lds_b32(src, byte_offset, base);
         load_to_lds_b32(src + plane, byte_offset, base + comp_bytes);
@@ -825,6 +897,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     };
     auto issue_window = [&](long long st, int buf) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds_offset_of(&win[w][buf][0][0]));
+        const unsigned e0 = first_entry();
+        const unsigned e1 = e0 ^ kWave;                    // the entry 64 further on
         if (((unsigned)st & (kTile - 1)) == 0u && st + kTile <= N) {
             // the common case - the window's tile is an aligned tile of Jt -: the tile goes into the scalar base address,
             // the lanes' offsets are the two per-lane constants, no vector arithmetic at all
@@ -857,6 +931,10 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     auto window_rmax = [&](long long st) -> float {
         if (!any_radius) return 0.0f;
         const int ta = __builtin_amdgcn_readfirstlane((int)(st / kTile));
+        if (kLog && (ta < 0 || ta + 1 >= NB_RING_LATE(n_tiles))) {
+            if (l == 0) atomicAdd(&NB_RING_LATE(ctr)->errors, kIndexError);
+            return __builtin_inff();                       // every lane is flagged: the general code decides
+        }
         const float ra = tile_rmax[ta], rb = tile_rmax[ta + 1];
         const float rw = (st + kTile > N) ? tile_rmax[0] : 0.0f;
         const float rab = ra > rb ? ra : rb;
@@ -884,7 +962,14 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
     // collision and not closer than 2^-40 then takes the scalar form of the fast chain - the same bits as the general
     // code's IEEE square root and reciprocal (nbody_selftest_ieee_f32) at a quarter of the instructions; a flagged
     // lane holds up its whole ring, so this path is worth keeping short.
-    auto general_turn = [&](int kind, int kk, long long st, int L, int off0, int buf, bool bounded) {
+    auto general_turn = [&](BodyAcc<T>& a, int kind, int kk, long long st, int L, int off0, int buf, bool bounded) {
+        const long long i64 = body_index64();
+        const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+        const T growth = NB_RING_LATE(p.growth);
+        Event* const ev = kLog ? NB_RING_LATE(ev) : nullptr;
+        const int ev_cap = kLog ? NB_RING_LATE(ev_cap) : 0;
+        Counters* const ctr = kLog ? NB_RING_LATE(ctr) : nullptr;
+        const int step = kLog ? meta->step : 0;
         if (kind == 2) {                                   // issued after the previous own turn's hand-off
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -892,6 +977,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
         const int hi = off0 + kT < L ? off0 + kT : L;
         int lane_entry = lit ? l : 0;                      // this lane's first window entry.  Computed HERE: hoisted out of
         asm volatile("" : "+v"(lane_entry));               // the turn loop it is one more register the fast path cannot spare
+        const int t = (int)(i64 - blk0);                   // threadIdx.x of the body in the reference
 #pragma unroll 1
         for (int off = off0; off < hi; ++off) {
             int sidx;
@@ -919,24 +1005,14 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                     continue;
                 }
             }
-            interact<T, kLog>(a, rec, p.growth, i, (int)j, ev, ev_cap, ctr, step);
+            interact<T, kLog>(a, rec, growth, i, (int)j, ev, ev_cap, ctr, step);
         }
     };
 
     long long st = tile_start_slow(w / kTurnsPerTile);
     int buf = 0;
-    int flags_in = 0;                                      // `flags` of the last record this wave received
     int plain_turns = 0;                                   // turns of this wave that took the common path
-    // {mnew, rnew, deleted} are only needed by the general code and the epilogue: brought up to date from the last
-    // received flags (and the rare record) right before those, never on the fast path
-    auto sync_rare = [&]() {
-        a.deleted = flags_in & 1;
-        if ((flags_in >> 1) != mver) {                     // this lane's mass / radius changed in an earlier turn
-            const Float2 hm = *hand_m_l;
-            a.mnew = hm.x; a.rnew = hm.y;
-            mver = flags_in >> 1;
-        }
-    };
+    bool first_plain = false;                              // ... the first turn of the walk among them (one pair less)
     int kind = turn_kind(w, st);
     if (kind == 1) issue_window(st, buf);
     if (kind == 2) issue_truncated(st, tile_len(w / kTurnsPerTile, st));
@@ -969,14 +1045,14 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             const float* wx = &win[w][buf][0][lit ? l : 0];
             const float* wy = wx + kWin;
             const float* wm = wx + 2 * kWin;
-            const V2 ownx = {a.xi, a.xi}, owny = {a.yi, a.yi};
+            const V2 ownx = {xi, xi}, owny = {yi, yi};
             // Collision / tiny-distance screen, half an instruction per pair: a pair may only take the fast chain if it is
             // no collision, d2 > (ri + rj)^2, and d2 > 2^-80 (the proved domain).  With R = |ri| + (largest |radius| the
             // window can hold) every such pair has d2 > fma(R, R, 2^-80), a per-LANE constant of the turn, so the
             // SMALLEST d2 of the lane's kT pairs decides for all of them (d2 is finite here - the coordinates are
             // bounded - so no NaN can hide in the minimum; a NaN radius never collides and is not in the bound).  A
             // lane below the threshold is redone by the general code, which applies the exact predicate.
-            const float reach = abs_(a.ri) + cur.rmax;
+            const float reach = abs_(ri) + cur.rmax;
             const float threshold = __builtin_fmaf(reach, reach, kFastLo);
             float closest = kFastHi;
 #pragma unroll
@@ -1024,13 +1100,13 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 if (kSleep > 0) __builtin_amdgcn_s_sleep(kSleep);
             }
             if (kProbe) pr_polls += spins + 1;
-            flags_in = h.w;
         }
         if (kProbe) pt2 = __builtin_readcyclecounter();
         // (4) + (5).  The common case - a fast turn, no flagged lane, the sequence number the expected one - is kept as
         // short as the arithmetic allows, because it is the serial part of the whole workgroup: 2 kT dependent adds
         // (x and y chains interleaved: scalar adds need no wait states between dependent instructions, packed ones
-        // do), then one LDS write; `flags` passes through untouched.
+        // do), then one LDS write; `flags` passes through untouched.  The last turn publishes too: the epilogue takes the
+        // final state from the records.
         const bool plain = fast && flag == 0ull && !dead && !timed_out && __ballot(h.z != tau) == 0ull;
         if (__builtin_expect(plain, 1)) {
             float fx = __int_as_float(h.x), fy = __int_as_float(h.y);
@@ -1040,15 +1116,20 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 asm("" : "+v"(fx));                        // keeps hipcc from pairing the two adds into one v_pk_add_f32
                 fy = fy + ((r & 1) ? termy[r / 2].y : termy[r / 2].x);
             }
-            if (tau + 1 < nturns)
-                *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, flags_in};
+            *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, h.w};
             __builtin_amdgcn_s_setprio(0);
-            a.fx = fx; a.fy = fy;
             plain_turns += 1;                              // a scalar: kT pairs per active lane, added up at the end
-            if (first && active) pairs -= 1;
+            first_plain = first_plain || first;
         } else {
+            // the lane's whole state, for the general code: position and radius from the registers, the running sum and
+            // `deleted` from the record just received, {mnew, rnew, mi} from the rare record (its last writer published
+            // it before the sequence number this wave has seen)
+            BodyAcc<T> a;
+            a.xi = xi; a.yi = yi; a.ri = ri;
             a.fx = __int_as_float(h.x); a.fy = __int_as_float(h.y);
-            sync_rare();
+            a.deleted = h.w & 1;
+            const Float4 hm = *hand_m_l;
+            a.mnew = hm.x; a.rnew = hm.y; a.mi = hm.z;
             timeouts += timed_out ? 1 : 0;
             dead = dead || timed_out || __ballot(h.z >= kRingDeadSeq) != 0ull;
             const unsigned m_before = __float_as_uint(a.mnew), r_before = __float_as_uint(a.rnew);
@@ -1068,7 +1149,8 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                     const T yf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.yi), fl));
                     const T mf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.mi), fl));
                     const T rf = __int_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(a.ri), fl));
-                    const int r = l & (kT - 1);
+                    int r = l & (kT - 1);                                       // formed HERE (see general_turn's lane_entry)
+                    asm volatile("" : "+v"(r));
                     const Rec<T> rec = window_record(&win[w][buf][0][0], kWin, (lit ? fl : 0) + r);
                     const T dx = rec.x - xf, dy = rec.y - yf;
                     const T d2 = (dx * dx) + (dy * dy);
@@ -1082,7 +1164,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 }
                 if (active) {
                     if (odd) {
-                        general_turn(1, kk, st, L, off0, buf, true);
+                        general_turn(a, 1, kk, st, L, off0, buf, true);
                     } else {
                         float fx = a.fx, fy = a.fy;
 #pragma unroll
@@ -1097,6 +1179,7 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                         unsigned rest = hits;                                      // the collisions themselves, in walk order
                         int lane_entry = lit ? l : 0;
                         asm volatile("" : "+v"(lane_entry));                       // (see general_turn)
+                        const T growth = NB_RING_LATE(p.growth);
                         while (rest != 0u) {
                             const int r = __builtin_ctz(rest);
                             rest &= rest - 1u;
@@ -1104,27 +1187,32 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                             const bool ge = a.mi >= rec.m;
                             if (ge) {                                              // :215-221
                                 a.mnew = a.mnew + rec.m;
-                                a.rnew = a.rnew + rec.r * p.growth;
+                                a.rnew = a.rnew + rec.r * growth;
                             } else {                                               // :222-226
                                 a.deleted = 1;
                             }
                             if (kLog) {
-                                long long j = lit ? st + ((t + off0 + r) & (kTile - 1)) : st + off0 + r;
+                                const long long i64 = body_index64();
+                                const int i = (int)(i64 < 0x7fffffff ? i64 : 0x7fffffff);
+                                long long j = lit ? st + (((int)(i64 - blk0) + off0 + r) & (kTile - 1)) : st + off0 + r;
                                 if (j >= N) j %= N;
+                                Counters* const ctr = NB_RING_LATE(ctr);
                                 const unsigned long long slot = atomicAdd(&ctr->events, 1ull);
-                                if (slot < (unsigned long long)ev_cap) ev[slot] = Event{step, i, (int)j, ge ? 0 : 1};
+                                if (slot < (unsigned long long)NB_RING_LATE(ev_cap))
+                                    NB_RING_LATE(ev)[slot] = Event{meta->step, i, (int)j, ge ? 0 : 1};
                             }
                         }
                     }
-                    pairs += kT - (first ? 1 : 0);
+                    pairs_rare += kT - (first ? 1 : 0);
                 }
             } else if (active) {
-                general_turn(kind, kk, st, L, off0, buf, false);
+                general_turn(a, kind, kk, st, L, off0, buf, false);
                 const int hi = off0 + kT < L ? off0 + kT : L;
                 if (lit) {
-                    if (hi > off0) pairs += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
+                    if (hi > off0) pairs_rare += (hi - off0) - ((kk == 0 && off0 == 0) ? 1 : 0);
                 } else {
-                    for (int off = off0; off < hi; ++off) pairs += (st + off != i64) ? 1 : 0;
+                    const long long i64 = body_index64();
+                    for (int off = off0; off < hi; ++off) pairs_rare += (st + off != i64) ? 1 : 0;
                 }
             }
             if (dead) {                                    // a hand-off wait gave up somewhere before: poison, never a result
@@ -1132,14 +1220,10 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
                 a.deleted = 0;
             }
             // publish: the rare record first, then the one the next wave polls (a wave's LDS operations execute in order)
-            if (__float_as_uint(a.mnew) != m_before || __float_as_uint(a.rnew) != r_before) {
-                *hand_m_l = Float2{a.mnew, a.rnew};
-                mver += 1;
-            }
-            flags_in = (mver << 1) | (a.deleted & 1);      // what this wave now knows to be current
-            if (tau + 1 < nturns)
-                *hand_l = Int4{(int)__float_as_uint(a.fx), (int)__float_as_uint(a.fy), dead ? kRingDeadSeq : tau + 1,
-                               flags_in};
+            if (__float_as_uint(a.mnew) != m_before || __float_as_uint(a.rnew) != r_before)
+                *hand_m_l = Float4{a.mnew, a.rnew, a.mi, 0.0f};
+            *hand_l = Int4{(int)__float_as_uint(a.fx), (int)__float_as_uint(a.fy), dead ? kRingDeadSeq : tau + 1,
+                           a.deleted & 1};
             __builtin_amdgcn_s_setprio(0);
         }
         if (kProbe) pt3 = __builtin_readcyclecounter();
@@ -1154,14 +1238,26 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             pr_check += __builtin_readcyclecounter() - pt3;
         }
     }
-    if ((nturns - 1) % kW == w) sync_rare();               // the wave of the last turn holds the final state
     // Nothing above this line in the loop is a memory access the compiler tracks in vmcnt (the window loads and the
     // general code's record loads are inline assembly with their own waits): hipcc therefore places no vmcnt wait in
     // the loop, and the only one there is check_window's, for a prefetch issued a whole turn earlier.
-    if (mine && (nturns - 1) % kW == w) {                  // the wave that took the last turn: epilogue
-        const int q = i - lo;
-        const Vec2<T> v = Vown[q];
-        if (active) {
+    if (mine && (nturns - 1) % kW == w) {                  // the wave that took the last turn: epilogue, from the records it
+        const long long i64 = body_index64();              // has just written (a wave's LDS operations execute in order)
+        const int q = (int)(i64 - lo);
+        const Int4 hf = *hand_l;
+        const Float4 hm = *hand_m_l;
+        BodyAcc<T> a;
+        a.xi = xi; a.yi = yi; a.ri = ri; a.mi = hm.z;
+        a.fx = __int_as_float(hf.x); a.fy = __int_as_float(hf.y);
+        a.mnew = hm.x; a.rnew = hm.y; a.deleted = hf.w & 1;
+        Rec<T>* const S_J = NB_RING_LATE(S_J);
+        Vec2<T>* const S_V = NB_RING_LATE(S_V);
+        const bool q_ok = q >= 0 && q < NB_RING_LATE(cap_own);
+        const Vec2<T> v = q_ok ? NB_RING_LATE(Vown)[q] : Vec2<T>{0, 0};
+        if (!q_ok) {
+            atomicAdd(&NB_RING_LATE(ctr)->errors, kIndexError);
+        } else if (active) {
+            const StepParams<T> p = NB_RING_LATE(p);
             Rec<T> out; Vec2<T> vout;
             finish_body<T>(a, v, p, out, vout);
             S_J[q] = out;
@@ -1171,11 +1267,15 @@ void forces_ring_f32(const Rec<float>* __restrict__ J, const Vec2<float>* __rest
             S_V[q] = v;
         }
     }
-    if (active) pairs += (unsigned long long)plain_turns * kT;
+    Counters* const ctr = NB_RING_LATE(ctr);
+    unsigned long long pairs = 0;
+    if (active) pairs = (unsigned long long)((long long)plain_turns * kT - (first_plain ? 1 : 0) + pairs_rare);
     if (timeouts != 0 && l == 0) atomicAdd(&ctr->errors, (unsigned long long)timeouts);
     for (int sh = kWave / 2; sh > 0; sh >>= 1) pairs += __shfl_down(pairs, sh, kWave);
     if (l == 0 && pairs) atomicAdd(&ctr->pairs, pairs);
     if (kProbe && l == 0) {
+        Event* const ev = NB_RING_LATE(ev);
+        const int ev_cap = NB_RING_LATE(ev_cap);
         atomicAdd(&ctr->probe[0], pr_eval); atomicAdd(&ctr->probe[1], pr_wait);
         atomicAdd(&ctr->probe[2], pr_chain); atomicAdd(&ctr->probe[3], pr_check);
         atomicAdd(&ctr->probe[4], pr_polls);
