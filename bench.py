@@ -47,7 +47,8 @@ def measured_traffic(a, world):
     as MI355X_MICROARCH.md prescribes).  Only reported for the configuration it was measured on; the JSON line
     names the file it came from."""
     path = os.path.join(ROOT, TRAFFIC_FILE)
-    if world != 1 or a.bodies != 262144 or a.fp64 or a.stock_radii or a.variant != 0 or not os.path.exists(path):
+    if (world != 1 or a.bodies != 262144 or a.fp64 or a.stock_radii or a.variant != 0 or a.clean or
+            not os.path.exists(path)):
         return None, None
     return json.load(open(path))["forces_kernel_traffic_bytes_per_launch"], TRAFFIC_FILE
 
@@ -62,7 +63,37 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
+def cpu_topology():
+    """Sockets, physical cores and logical CPUs of the host (/proc/cpuinfo), and the CPUs this process may run on:
+    BASELINE.md asks for the core count behind the CPU figure - OpenMP threads alone do not say whether they are
+    cores or SMT siblings."""
+    sockets, cores, logical = set(), set(), 0
+    phys = core = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            key, _, val = line.partition(":")
+            key, val = key.strip(), val.strip()
+            if key == "processor":
+                logical += 1
+                phys = core = None
+            elif key == "physical id":
+                phys = val
+                sockets.add(val)
+            elif key == "core id":
+                core = val
+            if phys is not None and core is not None:
+                cores.add((phys, core))
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = logical
+    return {"sockets": len(sockets) or None, "physical_cores": len(cores) or None, "logical_cpus": logical or None,
+            "cpus_usable_by_this_process": usable}
+
+
+def cpu_baseline(nb, bodies, cfg, budget_s=12.0, semantics=0):
     """Times the CPU oracle (oracle/nbody_oracle.c, OpenMP over i) on a bounded sample of the same workload:
     a contiguous range of i-bodies of step 1, every one against all its j's.  Checker used as the reported
     baseline only (kind 'port': the reference has no CPU stepper)."""
@@ -77,7 +108,7 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
         dt, gr = float(dt), float(gr)
     probe = min(n, 4 * threads)
     t0 = time.perf_counter()
-    *_, st = ol.port_range(blk, n, 0, probe, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    *_, st = ol.port_range(blk, n, 0, probe, dt, cfg.fieldWidth, cfg.fieldHeight, gr, semantics=semantics)
     t_probe = time.perf_counter() - t0
     rate = st.pairs / max(t_probe, 1e-9)
     per_body = st.pairs / probe
@@ -86,34 +117,52 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0):
     lo = (n // 2 // 128) * 128
     lo = min(lo, n - count)
     t0 = time.perf_counter()
-    oP, oV, oM, oR, _, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    oP, oV, oM, oR, _, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr,
+                                          semantics=semantics)
     t = time.perf_counter() - t0
+    topo = cpu_topology()
     base = {"value": st.pairs / t, "unit": "body-pair-interactions/sec", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(),
+            "cpu_model": cpu_model(), "cpu_topology": topo,
+            "cores_note": "`cores` = OpenMP threads used; the host has %s socket(s), %s physical cores, %s logical CPUs, "
+                          "%s usable by this process" % (topo["sockets"], topo["physical_cores"], topo["logical_cpus"],
+                                                         topo["cpus_usable_by_this_process"]),
             "sample": "bodies [%d,%d) of step 1 at N=%d against all j (%d pairs, %.1f s, OpenMP %d threads)" %
                       (lo, lo + count, n, st.pairs, t, threads)}
     # the same restatement on ONE thread, about two seconds of it
     ol.port().oracle_set_threads(1)
     one = max(8, min(count, int(10.0 * rate / threads / per_body)))   # ~2 s: one thread is faster than rate / threads
     t0 = time.perf_counter()
-    *_, st1 = ol.port_range(blk, n, lo, lo + one, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
+    *_, st1 = ol.port_range(blk, n, lo, lo + one, dt, cfg.fieldWidth, cfg.fieldHeight, gr, semantics=semantics)
     t1 = time.perf_counter() - t0
     ol.port().oracle_set_threads(threads)
     base["single_thread"] = {"value": st1.pairs / t1, "unit": "body-pair-interactions/sec",
                              "sample": "bodies [%d,%d) of the same step (%d pairs, %.1f s)" % (lo, lo + one, st1.pairs, t1)}
-    return base, parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR)
+    return base, parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR, semantics)
 
 
-def parity_of_ranks(nb, st, bodies, cfg, precision, device, total_steps, rank):
+def parity_of_ranks(nb, st, bodies, cfg, precision, device, total_steps, rank, semantics=0, dist=None):
     """world > 1: the state the ranks hold after the run (collective download over RCCL: every rank calls it) against
     a fresh SINGLE-rank stepper run for the same number of steps on rank 0's GPU.  Sharding changes who computes a
     body, never what is computed, so the bar is bitwise equality; the single-rank path is the one the 1-GPU line checks
     against the CPU oracle."""
     import numpy as np
+    if dist is not None:
+        # The download is a collective: a rank whose context has already failed must not leave the others waiting in
+        # it.  Every rank looks at its own context first and all agree (gloo) on whether to go in.
+        import torch
+        try:
+            st.sync()
+            ok = 1
+        except nb.NbodyError:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            raise RuntimeError("a rank's context reports a device failure: collective download skipped on every rank")
     got = st.download()
     if rank != 0:
         return None
-    one = nb.Stepper(cfg, precision=precision, device=device)
+    one = nb.Stepper(cfg, precision=precision, device=device, semantics=semantics)
     one.upload(bodies)
     one.step(total_steps)
     want = one.download()
@@ -158,12 +207,12 @@ def reference_kernels_on_gpu(nb, bodies, cfg, our_ms_per_step, steps=2):
             "this_framework_ms_per_step": our_ms_per_step, "speedup": (total_ms / steps) / our_ms_per_step}
 
 
-def parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR):
+def parity_of_sample(nb, bodies, cfg, lo, count, oP, oV, oM, oR, semantics=0):
     """The second half of BASELINE.json's metric ("max-|dpos| vs ref"): the HIP path's state after step 1
     against the oracle's for the bodies the CPU leg just computed (outside the timed region).  The device
     compacts deleted bodies away, so post-step indices are mapped through the device's own deletion log."""
     import numpy as np
-    st = nb.Stepper(cfg, precision=bodies.precision, record_events=True, event_capacity=1 << 23)
+    st = nb.Stepper(cfg, precision=bodies.precision, record_events=True, event_capacity=1 << 23, semantics=semantics)
     st.upload(bodies)
     st.step(1)
     out = st.download()
@@ -204,6 +253,9 @@ def main():
     ap.add_argument("--bodies", type=int, default=262144)
     ap.add_argument("--stock-radii", action="store_true", help="radii 50-200 (collisions on) instead of 0")
     ap.add_argument("--fp64", action="store_true")
+    ap.add_argument("--clean", action="store_true",
+                    help="clean semantics (every body active, true all-pairs, j ascending: SURVEY.md 8 f4) instead of "
+                         "the reference's literal index semantics")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="world > 1: skip the comparison with a single-rank run")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
@@ -229,6 +281,12 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+
+    # Exactly ONE line goes to stdout: libraries write there too (RCCL prints a version banner when its first
+    # communicator comes up), so from here on file descriptor 1 is stderr and the JSON line goes to the saved one.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch                       # plumbing: rendezvous, barriers, device selection
     import ppa_nbody_collisions_amd as nb
@@ -257,8 +315,9 @@ def main():
     bodies = nb.init_bodies(cfg, precision)
     if a.force_comm and comm_id is None:
         comm_id = nb.comm_unique_id()
+    semantics = nb.CLEAN if a.clean else nb.LITERAL
     st = nb.Stepper(cfg, precision=precision, device=local_rank, rank=rank, world=world, comm_id=comm_id,
-                    kernel_variant=a.variant, force_comm=a.force_comm)
+                    kernel_variant=a.variant, force_comm=a.force_comm, semantics=semantics)
     st.upload(bodies)
 
     def barrier():
@@ -269,8 +328,9 @@ def main():
 
     st.step(a.warmup)
     barrier()
+    st.set_kernel_timing(True)          # creates the timing events HERE: the timed region only records them
     s0 = st.stats()
-    st.set_kernel_timing(True)
+    barrier()
     t0 = time.perf_counter()
     st.step(a.steps)
     st.sync()
@@ -309,11 +369,12 @@ def main():
             "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64" if a.fp64 else "f32",
             "data": "synthetic",
-            "config": {"workload": "%sN=%d bodies, %s, %s, reference initial condition (seed 1024), literal "
-                                   "reference step semantics, %d steps" %
-                                   (baseline_config_name(a), a.bodies, "fp64" if a.fp64 else "fp32",
+            "config": {"workload": "%sN=%d bodies, %s, %s, reference initial condition (seed 1024), %s step semantics, "
+                                   "%d steps" %
+                                   ("" if a.clean else baseline_config_name(a), a.bodies, "fp64" if a.fp64 else "fp32",
                                     "stock radii 50-200 (collisions on)" if a.stock_radii else "radii 0",
-                                    a.steps),
+                                    "CLEAN (every body active, true all-pairs: SURVEY.md 8 f4; not the reference's)"
+                                    if a.clean else "literal reference", a.steps),
                        "bodies_after": s1.n_bodies,
                        "parallelism": "range-partition x%d, RCCL slot all-gather per step" % world
                        if world > 1 else "single GPU"},
@@ -330,10 +391,22 @@ def main():
                                   "frac": FLOP_PER_PAIR * k_pairs / (k_ms * 1e-3) / 1e12 / peak_valu,
                                   "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": k_pairs}},
         }
+        if world > 1 or a.force_comm:
+            # where a multi-rank step goes: the force kernel and the slot all-gather are timed with HIP events on the
+            # context's stream (rank 0's), the rest is compaction / unpack / launch gaps / waiting for slower ranks
+            n_x = max(1, s1.exchange_launches)
+            x_ms = s1.exchange_ms / n_x
+            out["step_breakdown"] = {
+                "rank": 0, "force_kernel_ms": k_ms, "exchange_ms": x_ms,
+                "rest_ms": out["ms_per_step"] - k_ms - x_ms,
+                "exchange_bytes_received_per_step": (s1.exchange_bytes - s0.exchange_bytes) / max(1, a.steps),
+                "slot_bytes_per_rank_now": s1.slot_bytes_now,
+                "note": "exchange = one all-gather of {count | records | velocities} slots laid out for the live bound of "
+                        "the body count (24 B per body + 32 B header per rank)"}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(nb, bodies, cfg, a.cpu_budget, semantics)
             try:
-                ref_gpu = reference_kernels_on_gpu(nb, bodies, cfg, out["ms_per_step"])
+                ref_gpu = None if a.clean else reference_kernels_on_gpu(nb, bodies, cfg, out["ms_per_step"])
             except Exception as e:        # a baseline leg must never take the benchmark line down with it
                 ref_gpu = {"error": "%s: %s" % (type(e).__name__, e)}
             if ref_gpu is not None:
@@ -342,14 +415,14 @@ def main():
         # every rank takes part (the download is a collective); rank 0 compares and reports.  A failing check must
         # not take the measured line down with it: it is reported in the line instead.
         try:
-            par = parity_of_ranks(nb, st, bodies, cfg, precision, local_rank, a.warmup + a.steps, rank)
+            par = parity_of_ranks(nb, st, bodies, cfg, precision, local_rank, a.warmup + a.steps, rank, semantics, dist)
         except Exception as e:
             par = {"error": "%s: %s" % (type(e).__name__, e), "bitwise_equal": False}
         if rank == 0:
             out["parity" if world > 1 else "parity_rccl_path"] = par
             out["config"]["rccl_ranks"] = world
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     st.close()
     if dist is not None:
         dist.barrier()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define NBODY_ABI_VERSION 1
+#define NBODY_ABI_VERSION 2
 
 /* ---------------------------------------------------------------------------------------------------
  * Status codes
@@ -198,6 +198,11 @@ typedef struct nbody_stats {
     int64_t force_kernel_launches;
     int n_bodies;             /* current global body count                                             */
     int n_own;                /* bodies owned by this rank                                             */
+    double exchange_ms;       /* sum of the per-step slot all-gather durations, HIP events (0 if off or no exchange) */
+    int64_t exchange_launches;
+    int64_t exchange_bytes;   /* bytes this rank received through all-gathers since upload              */
+    int64_t slot_bytes_now;   /* bytes ONE rank contributes to the next step's all-gather (0: no exchange): follows */
+                              /* the live body count, not the capacity                                   */
 } nbody_stats;
 int nbody_get_stats(nbody_ctx* ctx, nbody_stats* out);  /* synchronises */
 /* Bracket every force-kernel launch with HIP events on the context's stream (bench / profiling). */
@@ -271,6 +276,12 @@ int nbody_selftest_ieee_f32(int device, uint64_t mismatches[3]);
  * sqrt and 1/x on inputs_per_mode inputs of each of three families of its guarded domain [2^-500, 2^500] (random;
  * mantissas next to powers of two; perfect squares +- 4 ulps).  mismatches = {sqrt, 1/d^3}; both must be 0. */
 int nbody_selftest_chain_f64(int device, uint64_t inputs_per_mode, uint64_t mismatches[2]);
+/* The one known exception of Newton-type fp64 reciprocals (a significand of all ones: the last fma sees an exact tie and
+ * rounds one ulp low), on c = (2 - 2^-52) 2^k for every k in [-750, 750] against the closed form 2^-(k+1) (1 + 2^-52):
+ * result = {mismatches of the general code's reciprocal (must be 0), of the compiler's bare 1.0 / c (informational), of
+ * the fast chain's refinement (informational: the reason the fp64 kernel screens such c and redoes them with the general
+ * code), inputs the kernel's screen would miss (must be 0), inputs checked (1501)}. */
+int nbody_selftest_rcp_ones_f64(int device, uint64_t result[5]);
 
 /* The ring kernel's hand-off relies on a lane's 16-byte LDS record being written (ds_write_b128) and read
  * (ds_read_b128) in one LDS-array cycle, i.e. never seen half old, half new.  512 workgroups: one wave rewrites its 64

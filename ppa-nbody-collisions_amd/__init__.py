@@ -64,7 +64,9 @@ class _CtxDesc(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("steps", ctypes.c_int64), ("pairs", ctypes.c_int64), ("force_kernel_ms", ctypes.c_double),
-                ("force_kernel_launches", ctypes.c_int64), ("n_bodies", ctypes.c_int), ("n_own", ctypes.c_int)]
+                ("force_kernel_launches", ctypes.c_int64), ("n_bodies", ctypes.c_int), ("n_own", ctypes.c_int),
+                ("exchange_ms", ctypes.c_double), ("exchange_launches", ctypes.c_int64),
+                ("exchange_bytes", ctypes.c_int64), ("slot_bytes_now", ctypes.c_int64)]
 
 
 class Rng(ctypes.Structure):
@@ -127,6 +129,7 @@ SYMBOLS = {
     "nbody_launch_workspace_release": (_i, []),
     "nbody_selftest_ieee_f32": (_i, [_i, ctypes.POINTER(ctypes.c_uint64 * 3)]),
     "nbody_selftest_chain_f64": (_i, [_i, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64 * 2)]),
+    "nbody_selftest_rcp_ones_f64": (_i, [_i, ctypes.POINTER(ctypes.c_uint64 * 5)]),
     "nbody_selftest_lds_record": (_i, [_i, _i, ctypes.POINTER(ctypes.c_uint64 * 3)]),
     "nbody_debug_ring_probe": (_i, [_vp, ctypes.POINTER(ctypes.c_uint64 * 8)]),
     "nbody_debug_force_only": (_i, [_vp, _i]),

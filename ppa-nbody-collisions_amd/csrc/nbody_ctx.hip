@@ -131,15 +131,34 @@ struct nbody_ctx {
     bool device_failed = false;     // sticky until the next nbody_upload: a kernel reported a failed hand-off wait
     int n_upper = 0;            // host-side upper bound of the global count (exact after a sync)
     int own_upper = 0;          // upper bound of the own count
+    // The slot layout of a step - records | velocities of at most `U` bodies per rank - must be the SAME on every rank,
+    // so it may only depend on values every rank sees identically: the count at upload and the count after the step
+    // kLag steps back, whose Meta copy the host WAITS for (long landed by then) instead of looking at whatever has
+    // arrived.  A count only shrinks, so the older one bounds the current one.
+    static constexpr int kLag = 4;
+    struct Landed {
+        hipEvent_t ev = nullptr;            // recorded behind the copy
+        unsigned char* block = nullptr;     // pinned: Meta | Counters as of the end of step `step`
+        int64_t step = -1;
+    };
+    Landed lag[kLag];
+    int64_t enq = 0;            // steps enqueued since upload (index of the next step)
+    int xchg_n = 0;             // the deterministic bound of the body count (see above)
+    nbody_ctx** peers = nullptr;    // group contexts: every rank of the partition, set for the duration of a group call
+    int64_t xchg_bytes = 0;     // bytes this rank received through the exchange since upload
     bool uploaded = false;
     int64_t steps = 0;
     // RCCL
     void* comm = nullptr;
     // kernel timing
     bool timing = false;
-    std::vector<hipEvent_t> ev_pool;   // pairs (start, stop) not yet resolved
+    struct Timed { hipEvent_t e0, e1; int what; };        // what: 0 force kernel, 1 exchange
+    std::vector<Timed> ev_pending;     // recorded, not yet resolved
+    std::vector<hipEvent_t> ev_free;   // created by nbody_set_kernel_timing, outside any timed region
     double force_ms = 0.0;
     int64_t force_launches = 0;
+    double xchg_ms = 0.0;
+    int64_t xchg_launches = 0;
 };
 
 namespace {
@@ -171,17 +190,37 @@ StepParams<T> make_params(const nbody_ctx_desc& d, int spin_limit = 1 << 24) {
     return p;
 }
 
+// Timing events come from a pool that nbody_set_kernel_timing fills: nothing is created inside a timed region.  A pool
+// that runs dry resolves what is pending (a wait for the oldest launches) and reuses those events.
+constexpr int kTimingPool = 1024;
 int resolve_timing(nbody_ctx* c) {
-    for (size_t k = 0; k + 1 < c->ev_pool.size(); k += 2) {
+    for (const nbody_ctx::Timed& t : c->ev_pending) {
         float ms = 0.f;
-        HIP_TRY(hipEventSynchronize(c->ev_pool[k + 1]));
-        HIP_TRY(hipEventElapsedTime(&ms, c->ev_pool[k], c->ev_pool[k + 1]));
-        c->force_ms += ms;
-        c->force_launches += 1;
-        hipEventDestroy(c->ev_pool[k]);
-        hipEventDestroy(c->ev_pool[k + 1]);
+        HIP_TRY(hipEventSynchronize(t.e1));
+        HIP_TRY(hipEventElapsedTime(&ms, t.e0, t.e1));
+        if (t.what == 0) { c->force_ms += ms; c->force_launches += 1; }
+        else { c->xchg_ms += ms; c->xchg_launches += 1; }
+        c->ev_free.push_back(t.e0);
+        c->ev_free.push_back(t.e1);
     }
-    c->ev_pool.clear();
+    c->ev_pending.clear();
+    return NBODY_OK;
+}
+int timing_begin(nbody_ctx* c, int what, hipStream_t stream, nbody_ctx::Timed* t) {
+    if (c->ev_free.size() < 2) {
+        int rc = resolve_timing(c);
+        if (rc != NBODY_OK) return rc;
+    }
+    if (c->ev_free.size() < 2) return nbody_fail(NBODY_ERR_STATE, "timing is on but its event pool is empty");
+    t->e1 = c->ev_free.back(); c->ev_free.pop_back();
+    t->e0 = c->ev_free.back(); c->ev_free.pop_back();
+    t->what = what;
+    HIP_TRY(hipEventRecord(t->e0, stream));
+    return NBODY_OK;
+}
+int timing_end(nbody_ctx* c, hipStream_t stream, const nbody_ctx::Timed& t) {
+    HIP_TRY(hipEventRecord(t.e1, stream));
+    c->ev_pending.push_back(t);
     return NBODY_OK;
 }
 
@@ -198,6 +237,16 @@ int device_failure(nbody_ctx* c, unsigned long long errors) {
     return nbody_fail(NBODY_ERR_HIP, "device reported %llu in-kernel hand-off time-out(s) (the state is poisoned: NaN) and "
                                      "%llu failed index check(s) (the access was skipped): upload again",
                       errors % kIndexError, errors / kIndexError);
+}
+
+// Asynchronous look: errors of the step records that have landed so far.
+int landed_failure(nbody_ctx* c) {
+    unsigned long long errors = 0;
+    for (const nbody_ctx::Landed& L : c->lag)
+        if (L.step >= 0 && hipEventQuery(L.ev) == hipSuccess)
+            errors |= reinterpret_cast<const Counters*>(L.block + kCountersOffset)->errors;
+    (void)hipGetLastError();                               // hipErrorNotReady of a pending record is not an error
+    return device_failure(c, errors);
 }
 
 // Synchronises the stream and refreshes the host copies of Meta and Counters; fails if the device reported a failure.
@@ -311,29 +360,44 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
 
 template <typename T>
 int launch_force_kernel(nbody_ctx* c, const StepParams<T>& p, int nblocks) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    nbody_ctx::Timed t{};
     if (c->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, c->stream));
+        int rc = timing_begin(c, 0, c->stream, &t);
+        if (rc != NBODY_OK) return rc;
     }
     const bool log = (c->desc.flags & NBODY_FLAG_RECORD_EVENTS) != 0;
     launch_forces<T>(c, p, nblocks, log, own_target(c));
     HIP_TRY(hipGetLastError());
-    if (c->timing) {
-        HIP_TRY(hipEventRecord(e1, c->stream));
-        c->ev_pool.push_back(e0);
-        c->ev_pool.push_back(e1);
-    }
+    if (c->timing) return timing_end(c, c->stream, t);
     return NBODY_OK;
+}
+
+// Bodies per rank the slots of the NEXT step are laid out for, and the bytes one slot then takes in the exchange.
+int slot_bodies(const nbody_ctx* c) { return own_upper_of(c, c->xchg_n); }
+size_t slot_stride(const nbody_ctx* c) {
+    const size_t b = sizeof(SlotHeader) + (size_t)slot_bodies(c) * (c->rec_bytes + 2 * c->real_bytes);
+    return (b + 255) & ~(size_t)255;
+}
+
+// Before step `enq` is enqueued: the Meta copy of step enq - kLag is waited for and becomes the bound of this step.
+int refresh_bound(nbody_ctx* c) {
+    if (c->enq < nbody_ctx::kLag) return NBODY_OK;        // still the uploaded count
+    nbody_ctx::Landed& L = c->lag[c->enq % nbody_ctx::kLag];
+    if (L.step != c->enq - nbody_ctx::kLag) return nbody_fail(NBODY_ERR_STATE, "step record ring out of sequence");
+    HIP_TRY(hipEventSynchronize(L.ev));
+    const Meta* m = reinterpret_cast<const Meta*>(L.block);
+    const Counters* k = reinterpret_cast<const Counters*>(L.block + kCountersOffset);
+    if (m->n >= 0 && m->n < c->xchg_n) c->xchg_n = m->n;
+    if (c->xchg_n < c->n_upper) { c->n_upper = c->xchg_n; c->own_upper = own_upper_of(c, c->n_upper); }
+    return device_failure(c, k->errors);
 }
 
 template <typename T>
 int launch_compute(nbody_ctx* c) {
     const StepParams<T> p = make_params<T>(c->desc, c->spin_limit);
     {
-        const int n_seen = *(volatile int*)&c->h_meta_async->n;
-        if (n_seen > 0 && n_seen < c->n_upper) { c->n_upper = n_seen; c->own_upper = own_upper_of(c, n_seen); }
+        int rc = refresh_bound(c);
+        if (rc != NBODY_OK) return rc;
     }
     // Workgroups cover every reference block of the own range, which starts on a block boundary (nbody_own_range_of).  The
     // body count only shrinks between syncs, so the host-side upper bound is safe; the kernel takes the exact range
@@ -349,28 +413,69 @@ int launch_compute(nbody_ctx* c) {
                        (const Rec<T>*)c->S_J, (const Vec2<T>*)c->S_V, (const Meta*)c->meta,
                        (const int*)c->blk_counts, nblk, (SlotHeader*)c->slot,
                        (Rec<T>*)(c->slot + sizeof(SlotHeader)),
-                       (Vec2<T>*)(c->slot + sizeof(SlotHeader) + (size_t)c->cap_own * sizeof(Rec<T>)));
+                       (Vec2<T>*)(c->slot + sizeof(SlotHeader) + (size_t)slot_bodies(c) * sizeof(Rec<T>)));
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
 
 template <typename T>
 int launch_commit(nbody_ctx* c) {
-    const int gx = (c->own_upper + 255) / 256 > 0 ? (c->own_upper + 255) / 256 : 1;
-    // every rank's slot can hold up to cap_own survivors; own_upper bounds only OUR count, so size the
-    // grid by the largest count any rank can have
-    const int gx_all = c->desc.world > 1 ? (c->cap_own + 255) / 256 : gx;
+    // every rank's slot holds up to slot_bodies() survivors: the grid covers the largest count any rank can have
+    const int gx_all = (slot_bodies(c) + 255) / 256 > 0 ? (slot_bodies(c) + 255) / 256 : 1;
     hipLaunchKernelGGL((unpack_slots<T>), dim3(gx_all, c->desc.world), dim3(256), 0, c->stream,
-                       (const unsigned char*)c->gather, c->slot_bytes, c->cap_own, c->desc.world, c->desc.rank,
+                       (const unsigned char*)c->gather, slot_stride(c), slot_bodies(c), c->desc.world, c->desc.rank,
                        (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta, c->tile_rmax, c->Jt);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ONE all-gather interface, two transports.  Enqueued on c->stream: for every rank g, `bytes` bytes of rank g's `what`
+// land at dst + g * bytes of THIS rank.  RCCL contexts: one ncclAllGather (every rank calls it).  Group contexts (all
+// ranks are contexts of this process, c->peers): device-to-device copies out of the peers' buffers; the caller orders
+// them behind the peers' work (nbody_group_step's events, nbody_group_download's synchronisation).  Everything around
+// the transport - the slot layout, the unpack, the padded velocity gather and the Meta gather of a download - is the
+// same code for both, so the single-GPU group tests execute what a multi-GPU RCCL run executes, the ncclAllGather call
+// itself excepted.
+// ---------------------------------------------------------------------------------------------------------
+enum class Part { Slot, Velocities, MetaBlock };
+const unsigned char* part_of(const nbody_ctx* c, Part what) {
+    switch (what) {
+        case Part::Slot: return c->slot;
+        case Part::Velocities: return (const unsigned char*)c->Vown;
+        default: return (const unsigned char*)c->meta;
+    }
+}
+int all_gather(nbody_ctx* c, Part what, unsigned char* dst, size_t bytes) {
+    if (c->comm) {
+        RCCL_TRY(g_rccl.AllGather(part_of(c, what), dst, bytes, kNcclInt8, c->comm, c->stream));
+    } else if (c->desc.world == 1) {
+        if (dst != part_of(c, what))
+            HIP_TRY(hipMemcpyAsync(dst, part_of(c, what), bytes, hipMemcpyDeviceToDevice, c->stream));
+    } else if (c->peers) {
+        for (int g = 0; g < c->desc.world; ++g)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)g * bytes, part_of(c->peers[g], what), bytes, hipMemcpyDeviceToDevice,
+                                   c->stream));
+    } else {
+        return nbody_fail(NBODY_ERR_STATE, "context of a %d-rank partition has neither a communicator nor its peers",
+                          c->desc.world);
+    }
+    c->xchg_bytes += (int64_t)bytes * c->desc.world;
+    return NBODY_OK;
+}
+
+// The per-step exchange: every rank's slot {count | records | velocities}, laid out for slot_bodies() bodies - the
+// bound of the LIVE count, not the capacity: the gather shrinks with the body count.
 int do_exchange(nbody_ctx* c) {
-    if (c->gather == c->slot) return NBODY_OK;   // single rank: the gather buffer aliases the slot
-    if (!c->comm) return nbody_fail(NBODY_ERR_STATE, "context has no communicator");
-    RCCL_TRY(g_rccl.AllGather(c->slot, c->gather, c->slot_bytes, kNcclInt8, c->comm, c->stream));
+    if (c->gather == c->slot) return NBODY_OK;   // single rank without a communicator: the gather buffer IS the slot
+    nbody_ctx::Timed t{};
+    if (c->timing) {
+        int rc = timing_begin(c, 1, c->stream, &t);
+        if (rc != NBODY_OK) return rc;
+    }
+    int rc = all_gather(c, Part::Slot, c->gather, slot_stride(c));
+    if (rc != NBODY_OK) return rc;
+    if (c->timing) return timing_end(c, c->stream, t);
     return NBODY_OK;
 }
 
@@ -381,9 +486,12 @@ int commit_phase(nbody_ctx* c) {
     int rc = c->desc.precision == NBODY_F64 ? launch_commit<double>(c) : launch_commit<float>(c);
     if (rc != NBODY_OK) return rc;
     c->steps += 1;
-    // Counts only shrink, so a count read back late is still an upper bound: copy Meta to pinned memory
-    // without waiting and let later launches size their grids / pick their kernel from whatever has landed.
-    HIP_TRY(hipMemcpyAsync(c->h_meta_async, c->meta, kMetaBlockBytes, hipMemcpyDeviceToHost, c->stream));   // Meta and Counters
+    // Meta and Counters of this step go to a pinned record; the step kLag steps on waits for it (refresh_bound)
+    nbody_ctx::Landed& L = c->lag[c->enq % nbody_ctx::kLag];
+    HIP_TRY(hipMemcpyAsync(L.block, c->meta, kMetaBlockBytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(L.ev, c->stream));
+    L.step = c->enq;
+    c->enq += 1;
     return NBODY_OK;
 }
 
@@ -391,7 +499,12 @@ void free_all(nbody_ctx* c) {
     if (!c) return;
     hipSetDevice(c->desc.device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : c->ev_pool) hipEventDestroy(e);
+    for (const nbody_ctx::Timed& t : c->ev_pending) { hipEventDestroy(t.e0); hipEventDestroy(t.e1); }
+    for (hipEvent_t e : c->ev_free) hipEventDestroy(e);
+    for (nbody_ctx::Landed& L : c->lag) {
+        if (L.ev) hipEventDestroy(L.ev);
+        if (L.block) hipHostFree(L.block);
+    }
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     hipFree(c->J); hipFree(c->Vown); hipFree(c->S_J); hipFree(c->S_V);
     if (c->gather && c->gather != c->slot) hipFree(c->gather);
@@ -489,7 +602,12 @@ int nbody_ctx_create(nbody_ctx** out, const nbody_ctx_desc* d) {
     // Meta and Counters share one device block (and one pinned host block): the per-step look at them is ONE copy
     CTX_TRY(hipMalloc((void**)&c->meta, kMetaBlockBytes));
     c->counters = reinterpret_cast<Counters*>(reinterpret_cast<unsigned char*>(c->meta) + kCountersOffset);
-    if (use_comm) CTX_TRY(hipMalloc((void**)&c->meta_all, sizeof(Meta) * (size_t)d->world));
+    if (use_comm || d->world > 1) CTX_TRY(hipMalloc((void**)&c->meta_all, sizeof(Meta) * (size_t)d->world));
+    for (nbody_ctx::Landed& L : c->lag) {
+        CTX_TRY(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+        CTX_TRY(hipHostMalloc((void**)&L.block, kMetaBlockBytes, hipHostMallocDefault));
+        memset(L.block, 0, kMetaBlockBytes);
+    }
     CTX_TRY(hipMalloc((void**)&c->events, sizeof(Event) * (size_t)c->ev_cap));
     // on the context's own stream and waited for: hipMemset() on device memory runs on the NULL stream and may
     // return before the fill has executed; the context's stream is non-blocking, so a late fill could land
@@ -588,12 +706,16 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
     HIP_TRY(hipMemsetAsync(c->counters, 0, sizeof(Counters), c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_upper = n; c->own_upper = own_upper_of(c, n);
+    c->xchg_n = n; c->enq = 0; c->xchg_bytes = 0;
+    for (nbody_ctx::Landed& L : c->lag) L.step = -1;
     memset(c->h_counters, 0, sizeof(Counters));
     memset(c->h_counters_async, 0, sizeof(Counters));
     c->device_failed = false;
     c->uploaded = true;
     c->steps = 0;
-    c->force_ms = 0; c->force_launches = 0;
+    int rt = resolve_timing(c);
+    if (rt != NBODY_OK) return rt;
+    c->force_ms = 0; c->force_launches = 0; c->xchg_ms = 0; c->xchg_launches = 0;
     return NBODY_OK;
 }
 
@@ -623,7 +745,7 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
                 }
             }
     for (int g = 0; g < world; ++g) {
-        int failed = device_failure(ctxs[g], *(volatile unsigned long long*)&ctxs[g]->h_counters_async->errors);
+        int failed = landed_failure(ctxs[g]);
         if (failed != NBODY_OK) return failed;
     }
     std::vector<hipEvent_t> ready(world), done(world);
@@ -651,11 +773,12 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
             nbody_ctx* c = ctxs[h];
             HIP_TRY(hipSetDevice(c->desc.device));
             if (world > 1) {
-                for (int g = 0; g < world; ++g) {
+                for (int g = 0; g < world; ++g)
                     if (g != h) HIP_TRY(hipStreamWaitEvent(c->stream, ready[g], 0));
-                    HIP_TRY(hipMemcpyAsync(c->gather + (size_t)g * c->slot_bytes, ctxs[g]->slot, c->slot_bytes,
-                                           hipMemcpyDeviceToDevice, c->stream));
-                }
+                c->peers = ctxs;
+                rc = do_exchange(c);                       // the same call an RCCL context makes, peer-copy transport
+                c->peers = nullptr;
+                if (rc != NBODY_OK) break;
                 HIP_TRY(hipEventRecord(done[h], c->stream));
             }
             rc = commit_phase(c);
@@ -670,25 +793,26 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
     return rc;
 }
 
-// Full state of a single-process group: replica of rank 0 plus every rank's own velocities.
+// Full state of a single-process group: rank 0 downloads exactly as a rank of an RCCL run does - replica, velocity
+// gather, Meta gather (nbody_download) -, with the peer-copy transport.  Every rank is synchronised first: the copies
+// read the peers' buffers.
 int nbody_group_download(nbody_ctx** ctxs, int world, void* block, int* n_out) {
     if (!ctxs || world < 1 || !block || !n_out) return nbody_fail(NBODY_ERR_INVALID, "nbody_group_download: bad argument");
-    int rc = nbody_download(ctxs[0], block, n_out);
-    if (rc != NBODY_OK) return rc;
-    const int n = *n_out;
-    const size_t rb = ctxs[0]->real_bytes;
-    unsigned char* V = (unsigned char*)block + 2 * rb * (size_t)n;
-    for (int g = 1; g < world; ++g) {
+    int n0 = -1;
+    for (int g = 0; g < world; ++g) {
         nbody_ctx* c = ctxs[g];
+        if (!c || c->desc.world != world || c->desc.rank != g || !c->uploaded)
+            return nbody_fail(NBODY_ERR_STATE, "nbody_group_download: context %d is not rank %d of %d (or not uploaded)", g, g, world);
         HIP_TRY(hipSetDevice(c->desc.device));
-        rc = read_meta(c);
+        int rc = read_meta(c);
         if (rc != NBODY_OK) return rc;
-        if (c->h_meta->n != n) return nbody_fail(NBODY_ERR_STATE, "group ranks disagree on the body count");
-        HIP_TRY(hipMemcpyAsync(V + 2 * rb * (size_t)c->h_meta->lo, c->Vown, (size_t)c->h_meta->cnt * 2 * rb,
-                               hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (g == 0) n0 = c->h_meta->n;
+        if (c->h_meta->n != n0) return nbody_fail(NBODY_ERR_STATE, "group ranks disagree on the body count");
     }
-    return NBODY_OK;
+    ctxs[0]->peers = ctxs;
+    int rc = nbody_download(ctxs[0], block, n_out);
+    ctxs[0]->peers = nullptr;
+    return rc;
 }
 
 int nbody_step(nbody_ctx* c, int nsteps) {
@@ -698,7 +822,7 @@ int nbody_step(nbody_ctx* c, int nsteps) {
         return nbody_fail(NBODY_ERR_STATE, "group context: step it with nbody_group_step");
     HIP_TRY(hipSetDevice(c->desc.device));
     // asynchronous: a device failure of an earlier step is reported as soon as its counters have landed
-    int failed = device_failure(c, *(volatile unsigned long long*)&c->h_counters_async->errors);
+    int failed = landed_failure(c);
     if (failed != NBODY_OK) return failed;
     for (int s = 0; s < nsteps; ++s) {
         int rc = compute_phase(c);
@@ -778,28 +902,36 @@ int nbody_download(nbody_ctx* c, void* block, int* n_out) {
         memcpy(M + rb * i, st + c->rec_bytes * i + 2 * rb, rb);
         memcpy(R + rb * i, st + c->rec_bytes * i + 3 * rb, rb);
     }
-    // velocities: own range from this rank; other ranks' through the slot machinery (padded all-gather)
+    // velocities: own range from this rank; other ranks' through the same all-gather interface as the step's exchange
     if (c->desc.world == 1 && !c->comm) {
         HIP_TRY(hipMemcpyAsync(V, c->Vown, (size_t)cnt * 2 * rb, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
-    } else if (c->comm) {
-        // padded all-gather of the own velocities into the slot receive area: world * cap_own vec2 entries
-        // always fit there (a slot holds cap_own records of 4 reals, a velocity is 2 reals)
-        RCCL_TRY(g_rccl.AllGather(c->Vown, c->gather, (size_t)c->cap_own * 2 * rb, kNcclInt8, c->comm,
-                                  c->stream));
+    } else if (c->comm || c->peers) {
+        // padded all-gather of the own velocities into the slot receive area: own_upper_of(n) vec2 entries per rank (n is
+        // exact and the same on every rank here: all have synchronised); world of them always fit there (a slot holds
+        // records of 4 reals + velocities of 2 reals for at least that many bodies)
+        const size_t vbytes = (size_t)own_upper_of(c, n) * 2 * rb;
+        if (vbytes * c->desc.world > c->slot_bytes * c->desc.world)
+            return nbody_fail(NBODY_ERR_CAPACITY, "velocity gather does not fit the slot area");
+        rc = all_gather(c, Part::Velocities, c->gather, vbytes);
+        if (rc != NBODY_OK) return rc;
         // every rank's {lo, cnt}: a second, tiny all-gather of the device-resident Meta (the slot headers hold
         // counts only after a step has run)
-        RCCL_TRY(g_rccl.AllGather(c->meta, c->meta_all, sizeof(Meta), kNcclInt8, c->comm, c->stream));
+        rc = all_gather(c, Part::MetaBlock, (unsigned char*)c->meta_all, sizeof(Meta));
+        if (rc != NBODY_OK) return rc;
         std::vector<Meta> h_all(c->desc.world);
         HIP_TRY(hipMemcpyAsync(h_all.data(), c->meta_all, sizeof(Meta) * c->desc.world, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         for (int g = 0; g < c->desc.world; ++g) {
-            HIP_TRY(hipMemcpy(V + 2 * rb * (size_t)h_all[g].lo,
-                              c->gather + (size_t)g * c->cap_own * 2 * rb, (size_t)h_all[g].cnt * 2 * rb,
-                              hipMemcpyDeviceToHost));
+            if (h_all[g].n != n || h_all[g].lo < 0 || h_all[g].cnt < 0 || (size_t)h_all[g].cnt * 2 * rb > vbytes ||
+                (long long)h_all[g].lo + h_all[g].cnt > n)
+                return nbody_fail(NBODY_ERR_STATE, "rank %d reports range [%d, +%d) of %d bodies, this rank has %d bodies",
+                                  g, h_all[g].lo, h_all[g].cnt, h_all[g].n, n);
+            HIP_TRY(hipMemcpy(V + 2 * rb * (size_t)h_all[g].lo, c->gather + (size_t)g * vbytes,
+                              (size_t)h_all[g].cnt * 2 * rb, hipMemcpyDeviceToHost));
         }
     } else {
-        // group context: only the own range lives here; nbody_group_download assembles the rest
+        // a group context on its own: only the own range lives here; nbody_group_download assembles the whole state
         memset(V, 0, 2 * rb * (size_t)n);
         HIP_TRY(hipMemcpyAsync(V + 2 * rb * (size_t)lo, c->Vown, (size_t)cnt * 2 * rb, hipMemcpyDeviceToHost,
                                c->stream));
@@ -861,6 +993,13 @@ int nbody_clear_events(nbody_ctx* c) {
 
 int nbody_set_kernel_timing(nbody_ctx* c, int enable) {
     if (!c) return nbody_fail(NBODY_ERR_INVALID, "NULL context");
+    HIP_TRY(hipSetDevice(c->desc.device));
+    if (enable)                                            // the events of the timed launches are created HERE
+        while (c->ev_free.size() + 2 * c->ev_pending.size() < (size_t)kTimingPool) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            c->ev_free.push_back(e);
+        }
     c->timing = enable != 0;
     return NBODY_OK;
 }
@@ -878,6 +1017,10 @@ int nbody_get_stats(nbody_ctx* c, nbody_stats* out) {
     out->force_kernel_launches = c->force_launches;
     out->n_bodies = c->h_meta->n;
     out->n_own = c->h_meta->cnt;
+    out->exchange_ms = c->xchg_ms;
+    out->exchange_launches = c->xchg_launches;
+    out->exchange_bytes = c->xchg_bytes;
+    out->slot_bytes_now = c->gather == c->slot ? 0 : (int64_t)slot_stride(c);
     return NBODY_OK;
 }
 
@@ -1085,6 +1228,24 @@ int nbody_selftest_chain_f64(int device, uint64_t inputs_per_mode, uint64_t mism
     hipFree(d);
     mismatches[0] = h[0];
     mismatches[1] = h[1];
+    return NBODY_OK;
+}
+
+int nbody_selftest_rcp_ones_f64(int device, uint64_t result[5]) {
+    if (!result) return nbody_fail(NBODY_ERR_INVALID, "nbody_selftest_rcp_ones_f64: NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return nbody_fail(NBODY_ERR_NO_DEVICE, "no HIP device visible");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 5 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d, 0, 5 * sizeof(unsigned long long), 0));
+    hipLaunchKernelGGL(selftest_rcp_ones_f64, dim3(6), dim3(256), 0, 0, d);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[5];
+    HIP_TRY(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    hipFree(d);
+    for (int k = 0; k < 5; ++k) result[k] = h[k];
     return NBODY_OK;
 }
 

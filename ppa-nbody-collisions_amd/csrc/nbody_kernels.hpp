@@ -91,6 +91,26 @@ template <typename T> __device__ __forceinline__ T ieee_sqrt(T x);
 template <> __device__ __forceinline__ float ieee_sqrt<float>(float x) { return __builtin_sqrtf(x); }
 template <> __device__ __forceinline__ double ieee_sqrt<double>(double x) { return __builtin_sqrt(x); }
 
+// 1 / c, correctly rounded (vec2f.h:52 / vec2.h:48: `1.0f / val`).  fp32: the compiler's expansion, proved on all 2^32 inputs
+// (nbody_selftest_ieee_f32).  fp64 cannot be enumerated, and Newton-type refinements - the compiler's expansion and
+// the fast chain below alike - have ONE known exception (Markstein): a significand of all ones, c = (2 - 2^-52) 2^k.
+// There 1 / c = 2^-(k+1) (1 + 2^-53 + 2^-106 + ...) lies 2^-107 relative ABOVE the midpoint of two neighbours and the
+// last fma of the refinement sees an exact tie, which it rounds to even - one ulp low.  The correctly rounded value is
+// known in closed form, 2^-(k+1) (1 + 2^-52), and is written down for that significand (nbody_selftest_rcp_ones_f64).
+template <typename T> __device__ __forceinline__ T ieee_rcp(T c);
+template <> __device__ __forceinline__ float ieee_rcp<float>(float c) { return 1.0f / c; }
+constexpr unsigned long long kF64Frac = 0x000fffffffffffffull;
+__device__ __forceinline__ bool significand_all_ones(double c) {
+    return ((unsigned long long)__double_as_longlong(c) & kF64Frac) == kF64Frac;
+}
+template <> __device__ __forceinline__ double ieee_rcp<double>(double c) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(c);
+    const unsigned long long e = (b >> 52) & 0x7ffull;    // biased exponent; the result's is 2045 - e
+    if (significand_all_ones(c) && e >= 1 && e <= 2044)
+        return __longlong_as_double((long long)((b & 0x8000000000000000ull) | ((2045ull - e) << 52) | 1ull));
+    return 1.0 / c;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // One (i, j) interaction, SURVEY.md A.1 step 2 (src/nbody.cu:210-239, include/vec2f.h:45-93).
 // ---------------------------------------------------------------------------------------------------------
@@ -129,7 +149,7 @@ __device__ __forceinline__ void interact(BodyAcc<T>& a, const Rec<T>& bj, T grow
     // :230-239 (a NaN mass with hit falls through to here, as in the reference's if / else-if)
     const T d = ieee_sqrt<T>(d2);       // same operands, same rounding as the recomputation at :232
     const T c = (d * d) * d;
-    const T inv = (T)1.0f / c;          // vec2f.h:52
+    const T inv = ieee_rcp<T>(c);       // vec2f.h:52
     const T mx = bj.m * dx;             // vec2f.h:45-47
     const T my = bj.m * dy;
     a.fx = a.fx + inv * mx;             // vec2f.h:52, :83-85
@@ -299,8 +319,12 @@ __device__ __forceinline__ FastChain fast_chain(float d2) {
 // for operands whose exponents keep every intermediate normal - d2 in [2^-500, 2^500], hence d^3 in
 // [2^-750, 2^750] - the scaling is by 2^0 and the fix-ups select the computed value, so the results are the same
 // bits.  Checked on the device against the compiler's sqrt and 1/x (csrc/tune/chain_probe_f64.hip: 1.3e10 random
-// and structured inputs; nbody_selftest_chain_f64 in the test-suite).  36 instead of 71 instructions per pair.
-struct FastChainD { double d, inv; };
+// and structured inputs; nbody_selftest_chain_f64 in the test-suite): SAMPLED, not proved.  36 instead of 71 instructions
+// per pair.  Known exception of the reciprocal (see ieee_rcp): c with a significand of all ones comes out one ulp low.
+// The kernels therefore never let such a pair through: the low word of every c goes into a running v_max3_u32 (half an
+// instruction per pair) and a chunk that has seen 0xffffffff there is redone by the general code (2^-32 of the pairs).
+struct FastChainD { double d, inv, c; };
+__device__ __forceinline__ double fast_rcp_cube(double c, double h1);
 __device__ __forceinline__ FastChainD fast_chain(double x) {
     const double y = __builtin_amdgcn_rsq(x);
     const double g0 = x * y;
@@ -313,6 +337,10 @@ __device__ __forceinline__ FastChainD fast_chain(double x) {
     const double d1 = __builtin_fma(-g2, g2, x);
     const double d = __builtin_fma(d1, h1, g2);
     const double c = (d * d) * d;
+    return FastChainD{d, fast_rcp_cube(c, h1), c};
+}
+// 1 / c for c = d^3, seeded from h1 = 1 / (2 d) to ~2^-50 (the square root's refinement leaves it)
+__device__ __forceinline__ double fast_rcp_cube(double c, double h1) {
     // 1 / c without a second transcendental (v_rcp_f64 costs about five fp64 multiplies on this chip): h1 is 1 / (2 sqrt x)
     // to ~2^-50, so 8 h1^3 is 1 / c to ~2^-47 - a far better seed than the instruction's ~2^-26 - and ONE Newton step plus
     // the final residual correction of the compiler's own expansion (the step that makes its result correctly rounded:
@@ -321,7 +349,7 @@ __device__ __forceinline__ FastChainD fast_chain(double x) {
     const double e0 = __builtin_fma(-c, q0, 1.0);
     const double q1 = __builtin_fma(q0, e0, q0);
     const double e1 = __builtin_fma(-c, q1, 1.0);
-    return FastChainD{d, __builtin_fma(e1, q1, q1)};
+    return __builtin_fma(e1, q1, q1);
 }
 
 // Two chains at once on 2-vectors, element-wise (the same operations per element as fast_chain, hence the same
@@ -373,12 +401,20 @@ __device__ __forceinline__ void fast_inv_cube2x2(Pair<float>::type d2a, Pair<flo
     inva = __builtin_elementwise_fma(fa, ra, ra);
     invb = __builtin_elementwise_fma(fb, rb, rb);
 }
-__device__ __forceinline__ Pair<double>::type fast_inv_cube2(Pair<double>::type d2) {
+// `ones`: running maximum of the low words of every c = d^3 the chain has inverted (see FastChainD)
+__device__ __forceinline__ Pair<double>::type fast_inv_cube2(Pair<double>::type d2, unsigned& ones) {
     Pair<double>::type inv;                                // no packed fp64 instructions: two scalar chains
-    inv.x = fast_chain(d2.x).inv;
-    inv.y = fast_chain(d2.y).inv;
+    const FastChainD a = fast_chain(d2.x), b = fast_chain(d2.y);
+    inv.x = a.inv;
+    inv.y = b.inv;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(ones) : "v"(ones), "v"((unsigned)__double_as_longlong(a.c)),
+        "v"((unsigned)__double_as_longlong(b.c)));
     return inv;
 }
+__device__ __forceinline__ Pair<float>::type fast_inv_cube2(Pair<float>::type d2, unsigned&) { return fast_inv_cube2(d2); }
+// wave mask of the lanes whose chunk must be redone because of it (fp32: none - its chain is proved on every input)
+__device__ __forceinline__ unsigned long long ones_mask(float, unsigned) { return 0ull; }
+__device__ __forceinline__ unsigned long long ones_mask(double, unsigned ones) { return __ballot(ones == 0xffffffffu); }
 
 // a + b as an instruction the SLP vectoriser cannot see: left alone it merges the two pairs' (dx^2 + dy^2) adds into
 // one v_pk_add_f32 and pays for it with three v_mov_b32 that gather the operands
@@ -1710,12 +1746,38 @@ __global__ __launch_bounds__(256) void selftest_chain_f64(unsigned long long* mi
         const FastChainD f = fast_chain(x);
         const double d = ieee_sqrt<double>(x);
         const double c = (d * d) * d;
-        const double inv = 1.0 / c;
+        const double inv = ieee_rcp<double>(c);
         bad_sqrt += __double_as_longlong(f.d) != __double_as_longlong(d);
         bad_inv += __double_as_longlong(f.inv) != __double_as_longlong(inv);
     }
     if (bad_sqrt) atomicAdd(&mism[0], bad_sqrt);
     if (bad_inv) atomicAdd(&mism[1], bad_inv);
+}
+
+// Device self-test of the one known exception of the fp64 reciprocal refinements (ieee_rcp): c = (2 - 2^-52) 2^k for every
+// exponent of the guarded domain of d^3, [2^-750, 2^750].  Expected: 2^-(k+1) (1 + 2^-52).  out[0]: mismatches of
+// ieee_rcp<double> (the general code; must be 0), out[1]: of the compiler's bare 1.0 / c (informational), out[2]: of the fast
+// chain's refinement from a seed as good as the kernels' (informational: this is WHY the kernels screen such c),
+// out[3]: inputs the screen (low word == 0xffffffff) would have missed (must be 0), out[4]: inputs checked.
+__global__ __launch_bounds__(256) void selftest_rcp_ones_f64(unsigned long long* out) {
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x) - 750;
+    if (k > 750) return;
+    const double c = __longlong_as_double((long long)(((unsigned long long)(k + 1023) << 52) | kF64Frac));
+    const double want = __longlong_as_double((long long)(((unsigned long long)(1023 - k - 1) << 52) | 1ull));
+    const double general = ieee_rcp<double>(c);
+    double bare;
+    {
+        double cc = c;
+        asm volatile("" : "+v"(cc));                       // the plain division, not folded
+        bare = 1.0 / cc;
+    }
+    const double d = ::cbrt(c);
+    const double fast = fast_rcp_cube(c, 0.5 / d);
+    atomicAdd(&out[0], (unsigned long long)(__double_as_longlong(general) != __double_as_longlong(want)));
+    atomicAdd(&out[1], (unsigned long long)(__double_as_longlong(bare) != __double_as_longlong(want)));
+    atomicAdd(&out[2], (unsigned long long)(__double_as_longlong(fast) != __double_as_longlong(want)));
+    atomicAdd(&out[3], (unsigned long long)((unsigned)__double_as_longlong(c) != 0xffffffffu || !significand_all_ones(c)));
+    atomicAdd(&out[4], 1ull);
 }
 
 }  // namespace nbk

@@ -89,6 +89,19 @@ def test_fp64_fast_chain_against_ieee(nb):
     assert (m[0], m[1]) == (0, 0)
 
 
+def test_fp64_reciprocal_of_all_ones_significand(nb):
+    """The one known exception of Newton-type fp64 reciprocals (Markstein): c = (2 - 2^-52) 2^k.  The last fma of the
+    refinement sees an exact tie and rounds one ulp low.  On every exponent of the guarded domain: the general code's
+    reciprocal (ieee_rcp: closed form for that significand) must be right, and the fp64 kernel's screen (low word of c
+    == 0xffffffff -> the chunk is redone by the general code) must catch every such c.  Informational: whether the
+    compiler's bare division and the fast refinement get them right (they need not: that is why the screen exists)."""
+    r = (ctypes.c_uint64 * 5)()
+    assert nb.lib.nbody_selftest_rcp_ones_f64(0, ctypes.byref(r)) == 0, nb.lib.nbody_last_error_string()
+    print("\nall-ones significands: %d inputs; general code wrong on %d, bare 1.0/c wrong on %d, fast refinement wrong on "
+          "%d, missed by the screen %d" % (r[4], r[0], r[1], r[2], r[3]))
+    assert r[4] == 1501 and r[0] == 0 and r[3] == 0
+
+
 def _stepper(nb, cap, fw, fh, dt=DT, growth=GROWTH, **kw):
     return nb.Stepper(capacity=cap, timestep=float(dt), growthRate=float(growth), fieldWidth=fw, fieldHeight=fh,
                       **kw)
@@ -607,6 +620,61 @@ def test_c5_shape_eight_ranks_equals_one(nb):
     assert np.array_equal(bits(a.block), bits(b.block))
     assert sum(r.stats().pairs for r in grp.ranks) == one.stats().pairs
     grp.close(); one.close()
+
+
+def test_exchange_follows_the_live_count(nb):
+    """The per-step all-gather moves slots laid out for the LIVE bound of the body count, not for the capacity: the bound
+    is the count kLag = 4 steps back (the host waits for that step's Meta, so every rank of an RCCL run derives the same
+    layout), it only shrinks, and the bytes received add up to exactly that.  4 ranks on one GPU, a dense field whose
+    count collapses; the group runs the same exchange / unpack code as RCCL contexts (peer-copy transport)."""
+    world, n0, field, lag = 4, 4096, 12000, 4
+    cfg = nb.stock_config(particleCount=n0, fieldWidth=field, fieldHeight=field)
+    bodies = nb.init_bodies(cfg)
+    one = nb.Stepper(cfg)
+    one.upload(bodies)
+    counts = []
+    for _ in range(14):
+        one.step(1)
+        counts.append(one.body_count())
+    assert counts[-1] < n0 - 512, "the case is meant to lose bodies: %r" % counts
+
+    def stride(n):
+        own_upper = ((n + 127) // 128 + world - 1) // world * 128
+        return (32 + own_upper * 24 + 255) // 256 * 256
+
+    grp = nb.StepperGroup(world, cfg=cfg)
+    grp.upload(bodies)
+    assert grp.ranks[1].stats().slot_bytes_now == stride(n0) and grp.ranks[1].stats().exchange_bytes == 0
+    expect = 0
+    for s in range(14):                                  # step s is laid out for the count after step s - lag
+        grp.step(1)
+        expect += world * stride(n0 if s < lag else counts[s - lag])
+        st = grp.ranks[s % world].stats()
+        assert st.exchange_bytes == expect, (s, st.exchange_bytes, expect)
+    assert grp.ranks[0].stats().slot_bytes_now == stride(counts[13 - lag]) < stride(n0)
+    a, b = grp.download(), one.download()
+    assert a.numBodies == b.numBodies == counts[-1] and np.array_equal(bits(a.block), bits(b.block))
+    # the download gathers velocities and Meta through the same interface: rank 0 received them
+    assert grp.ranks[0].stats().exchange_bytes > expect and grp.ranks[1].stats().exchange_bytes == expect
+    grp.close(); one.close()
+
+
+def test_group_context_alone_cannot_assemble_the_state(nb):
+    """A rank of a group has its own velocities only: downloading it by itself returns the replica with zero velocities
+    outside its range (documented), the group download returns the whole state."""
+    cfg = nb.stock_config(particleCount=1024, fieldWidth=5000, fieldHeight=5000)
+    bodies = nb.init_bodies(cfg)
+    grp = nb.StepperGroup(2, cfg=cfg)
+    grp.upload(bodies)
+    grp.step(3)
+    whole = grp.download()
+    lo, cnt = grp.ranks[1].own_range()
+    part = grp.ranks[1].download()
+    assert part.numBodies == whole.numBodies
+    assert np.array_equal(bits(part.Positions), bits(whole.Positions))
+    assert np.array_equal(bits(part.Velocities[lo:lo + cnt]), bits(whole.Velocities[lo:lo + cnt]))
+    assert not part.Velocities[:lo].any()
+    grp.close()
 
 
 def test_rccl_path_single_rank(nb):

@@ -42,7 +42,7 @@ def _product(nb, cfg, bodies, steps, **kw):
     (128, 3000, "stock", 12), (129, 3000, "stock", 12), (130, 3000, "stock", 12), (200, 3000, "stock", 12),   # 
     (255, 3000, "stock", 12), (257, 3000, "stock", 12), (4096, 20000, "stock", 30),
     (65536, 100000, "r0", 1000),       # C2 (BASELINE configs[1]) over its whole 1000-step horizon
-    (65536, 100000, "stock", 1000),    # C3 (configs[2]) over its whole horizon: the count collapses 65536 -> ~7.8k
+    (65536, 100000, "stock", 1000),    # C3 (configs[2]) over its whole horizon: the count collapses 65536 -> 137
     (262144, 100000, "r0", 25),        # C4 / the metric's configuration (its 1000 steps would take the reference 3.5 min)
     (262144, 100000, "stock", 10),
 ])
@@ -59,6 +59,36 @@ def test_product_equals_reference_kernels_bitwise(nb, n, field, radii, steps):
     assert np.array_equal(bits(out.block), bits(blk[:6 * n_ref])), "product != reference kernels after %d steps" % steps
     print("\nN=%d %s: %d steps, %d -> %d bodies; reference kernels %.2f ms per step on this GPU" %
           (n, radii, steps, n, n_ref, ms / steps))
+
+
+@pytest.mark.parametrize("radii,chunk", [("r0", 100), ("stock", 10)])
+def test_c4_whole_horizon_equals_reference_kernels(nb, radii, chunk):
+    """C4, the configuration BASELINE.json's metric is quoted on (N=262144, 1000 iterations of the loop src/nbody.cu:460-461
+    with the launches :481-483), over its WHOLE horizon: the product free-running beside the reference's own kernels on the
+    same GPU, whole state compared bit for bit every `chunk` steps.  north_star's "<= 1e-5 relative error vs the reference
+    over 1000 steps" is met with error 0 against this build of the reference's kernel text.  Radii 0 (the headline row):
+    about 205 s of reference kernels and 31 s of ours; stock radii (collisions on, 262144 -> 132 bodies): a few seconds."""
+    n, steps = 262144, 1000
+    kw = {"minRadius": 0.0, "maxRadius": 0.0} if radii == "r0" else {}
+    cfg = nb.stock_config(particleCount=n, **kw)
+    bodies = nb.init_bodies(cfg)
+    st = nb.Stepper(cfg)
+    st.upload(bodies)
+    st.set_kernel_timing(True)
+    blk = bodies.contiguousData.copy()
+    cur, ref_ms, done = n, 0.0, 0
+    while done < steps:
+        cur, ms, _ = ol.ref_hip_run(blk, cur, chunk, DT, cfg.fieldWidth, cfg.fieldHeight, GROWTH)
+        ref_ms += ms
+        st.step(chunk)
+        done += chunk
+        out = st.download()
+        assert out.numBodies == cur, "step %d: %d bodies, the reference's kernels have %d" % (done, out.numBodies, cur)
+        assert np.array_equal(bits(out.block), bits(blk[:6 * cur])), "product != reference kernels at step %d" % done
+    ours_ms = st.stats().force_kernel_ms
+    st.close()
+    print("\nC4 %s: 1000 steps, %d -> %d bodies, bit-identical every %d steps; kernel time: reference %.1f s, product %.2f s" %
+          (radii, n, cur, chunk, ref_ms / 1e3, ours_ms / 1e3))
 
 
 def test_reference_kernels_equal_cpu_oracle(nb):

@@ -126,7 +126,7 @@ def test_library_exports_every_declared_symbol(nb):
         assert hasattr(raw, name), "library does not export %s" % name
         assert name in nb.SYMBOLS, "python binding does not cover %s" % name
     assert set(nb.SYMBOLS) == declared
-    assert nb.lib.nbody_abi_version() == 1
+    assert nb.lib.nbody_abi_version() == 2
 
 
 def test_compute_fails_loudly_without_gpu(nb):
