@@ -53,10 +53,11 @@ struct Meta {
     int step;     // step counter since upload
     int n_prev;   // body count before the last step's compaction (the reference renders with its block count)
     int summary;  // of the replica: bit 0 some coordinate is not below kCoordBound in magnitude (or NaN), bit 1 some
-                  // radius is not +0.  OR-ed together by unpack_slots (cleared by compact_count), set by nbody_upload.
+                  // radius is not +0, bit 2 some coordinate is below kCoordFloor in magnitude (zero included).  OR-ed
+                  // together by unpack_slots (cleared by compact_count), set by nbody_upload.
     int pad[2];
 };
-constexpr int kSummaryUnbounded = 1, kSummaryRadius = 2;
+constexpr int kSummaryUnbounded = 1, kSummaryRadius = 2, kSummarySmall = 4;
 
 struct Event { int32_t step, i, j, kind; };
 
@@ -300,6 +301,16 @@ __global__ __launch_bounds__(kTile) void forces_v1(const Rec<T>* __restrict__ J,
 constexpr float kFastLo = 0x1p-80f;        // lower edge of the proved domain (and the flag margin)
 constexpr float kFastHi = 0x1p80f;         // upper edge of the proved domain
 constexpr float kCoordBound = 0x1p38f;     // |x|,|y| < 2^38 for both bodies  =>  d2 <= 2^79 < kFastHi
+// |x|,|y| >= 2^-16 for both bodies  =>  a coordinate difference is 0 or at least 2^-39 (the spacing of fp32 at 2^-16), so
+// d2 is exactly 0 or at least 2^-78: with all radii +0 the only pairs outside the fast chain's domain - and the only
+// collisions - are COINCIDENT bodies, and those turn their term into NaN (v_rsq_f32(0) = inf, 0 * inf = NaN): the ring
+// kernel then needs no screen per pair at all, it looks at the sum after the turn's adds (see its turn loop).
+constexpr float kCoordFloor = 0x1p-16f;
+__device__ __forceinline__ int coord_summary(float x, float y) {
+    const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+    return ((ax < kCoordBound && ay < kCoordBound) ? 0 : kSummaryUnbounded) |
+           ((ax >= kCoordFloor && ay >= kCoordFloor) ? 0 : kSummarySmall);
+}
 
 struct FastChain { float d, inv; };
 __device__ __forceinline__ FastChain fast_chain(float d2) {
@@ -788,6 +799,9 @@ void forces_ring_f32(const RingArgs args) {
     __shared__ Float4 hand_m_all[kRings][kWave];           // {mnew, rnew, mi, -}: rewritten only when mnew / rnew change
     const int N = meta->n, lo = meta->lo, cnt = meta->cnt;
     const bool all_bounded = (meta->summary & kSummaryUnbounded) == 0, any_radius = (meta->summary & kSummaryRadius) != 0;
+    // every coordinate of the replica in [2^-16, 2^38) and every radius +0: coincident bodies are the only pairs a fast
+    // turn must not add up, and they show as a NaN sum (kCoordFloor)
+    const bool nan_screen = meta->summary == 0;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
     const int ring = wv / kW;                              // which 64 bodies of the block
@@ -1076,8 +1090,11 @@ void forces_ring_f32(const RingArgs args) {
         }
         // (2) the kT terms of this turn: walk positions 2v, 2v + 1 in the two halves of termx[v] / termy[v]
         V2 termx[kT / 2], termy[kT / 2];
+        auto term_x = [&](int r) -> float { return (r & 1) ? termx[r / 2].y : termx[r / 2].x; };
+        auto term_y = [&](int r) -> float { return (r & 1) ? termy[r / 2].y : termy[r / 2].x; };
         unsigned long long flag = 0;
-        if (fast) {
+        auto evaluate = [&](auto screen_tag) {
+            constexpr bool kScreen = decltype(screen_tag)::value;     // false: no screen per pair (nan_screen)
             const float* wx = &win[w][buf][0][lit ? l : 0];
             const float* wy = wx + kWin;
             const float* wm = wx + 2 * kWin;
@@ -1102,9 +1119,11 @@ void forces_ring_f32(const RingArgs args) {
                 const V2 sxa = dxa * dxa, sxb = dxb * dxb;
                 const V2 sya = dya * dya, syb = dyb * dyb;
                 const V2 d2a = sxa + sya, d2b = sxb + syb; // three roundings per element (no contraction in this file)
-                const float first_d2 = (r0 == 0 && first) ? kFastHi : d2a.x;   // the self position is no pair
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(first_d2), "v"(d2a.y));
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2b.x), "v"(d2b.y));
+                if (kScreen) {
+                    const float first_d2 = (r0 == 0 && first) ? kFastHi : d2a.x;   // the self position is no pair
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(first_d2), "v"(d2a.y));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2b.x), "v"(d2b.y));
+                }
                 V2 inva, invb;
                 fast_inv_cube2x2(d2a, d2b, inva, invb);
                 const V2 txa = dxa * ma, txb = dxb * mb;
@@ -1115,10 +1134,14 @@ void forces_ring_f32(const RingArgs args) {
                 // and keeps both factors alive until then: twice the registers, spills)
                 asm volatile("" : "+v"(termx[r0 / 2]), "+v"(termx[r0 / 2 + 1]), "+v"(termy[r0 / 2]), "+v"(termy[r0 / 2 + 1]));
             }
-            flag = le_mask(closest, threshold);
+            if (kScreen) flag = le_mask(closest, threshold);
             // the reference skips the self position; the sum starts at +0.0f and +0 + +0 = +0: adding a zero term is
-            // the same bits (whatever the self "pair" evaluated to is dropped here)
+            // the same bits (whatever the self "pair" evaluated to - NaN: d2 = 0 - is dropped here)
             if (first) { termx[0].x = 0.0f; termy[0].x = 0.0f; }
+        };
+        if (fast) {
+            if (nan_screen) evaluate(std::false_type{});
+            else evaluate(std::true_type{});
         }
         if (kProbe) pt1 = __builtin_readcyclecounter();
         // (3) the state after turn tau - 1.  Polled at raised priority: a poll is one LDS read plus scalar work, it
@@ -1143,20 +1166,29 @@ void forces_ring_f32(const RingArgs args) {
         // (x and y chains interleaved: scalar adds need no wait states between dependent instructions, packed ones
         // do), then one LDS write; `flags` passes through untouched.  The last turn publishes too: the epilogue takes the
         // final state from the records.
-        const bool plain = fast && flag == 0ull && !dead && !timed_out && __ballot(h.z != tau) == 0ull;
+        bool plain = fast && flag == 0ull && !dead && !timed_out && __ballot(h.z != tau) == 0ull;
         if (__builtin_expect(plain, 1)) {
             float fx = __int_as_float(h.x), fy = __int_as_float(h.y);
 #pragma unroll
             for (int r = 0; r < kT; ++r) {
-                fx = fx + ((r & 1) ? termx[r / 2].y : termx[r / 2].x);
+                fx = fx + term_x(r);
                 asm("" : "+v"(fx));                        // keeps hipcc from pairing the two adds into one v_pk_add_f32
-                fy = fy + ((r & 1) ? termy[r / 2].y : termy[r / 2].x);
+                fy = fy + term_y(r);
             }
-            *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, h.w};
-            __builtin_amdgcn_s_setprio(0);
-            plain_turns += 1;                              // a scalar: kT pairs per active lane, added up at the end
-            first_plain = first_plain || first;
-        } else {
+            // nan_screen: a coincident pair (d2 = 0: a collision, :215-226) made its term NaN, and a NaN among the kT terms
+            // is a NaN sum.  ONE comparison per turn instead of a v_min3 per two pairs; a lane whose sum was NaN already is
+            // flagged in every turn (slow, and right: its collisions still have to be found).
+            if (nan_screen) flag = __builtin_amdgcn_fcmpf(fx, fy, 8 /* llvm::CmpInst::FCMP_UNO */);
+            if (__builtin_expect(flag == 0ull, 1)) {
+                *hand_l = Int4{(int)__float_as_uint(fx), (int)__float_as_uint(fy), tau + 1, h.w};
+                __builtin_amdgcn_s_setprio(0);
+                plain_turns += 1;                          // a scalar: kT pairs per active lane, added up at the end
+                first_plain = first_plain || first;
+            } else {
+                plain = false;                             // the sums are dropped: the turn is redone below from `h`
+            }
+        }
+        if (__builtin_expect(!plain, 0)) {
             // the lane's whole state, for the general code: position and radius from the registers, the running sum and
             // `deleted` from the record just received, {mnew, rnew, mi} from the rare record (its last writer published
             // it before the sequence number this wave has seen)
@@ -1169,6 +1201,10 @@ void forces_ring_f32(const RingArgs args) {
             timeouts += timed_out ? 1 : 0;
             dead = dead || timed_out || __ballot(h.z >= kRingDeadSeq) != 0ull;
             const unsigned m_before = __float_as_uint(a.mnew), r_before = __float_as_uint(a.rnew);
+            if (fast && nan_screen) {                      // (a turn that came here without its sums: every NaN term flags its lane)
+#pragma unroll
+                for (int r = 0; r < kT; ++r) flag |= __builtin_amdgcn_fcmpf(term_x(r), term_y(r), 8);
+            }
             if (fast) {
                 // The flagged lanes (a SUPERSET of the lanes with a collision or a tiny distance in this turn) get the exact
                 // status of each of their kT pairs, and they get it in parallel: lane r of the wave evaluates walk position r
@@ -1205,8 +1241,8 @@ void forces_ring_f32(const RingArgs args) {
                         float fx = a.fx, fy = a.fy;
 #pragma unroll
                         for (int r = 0; r < kT; ++r) {
-                            const float nx = add_unmerged(fx, (r & 1) ? termx[r / 2].y : termx[r / 2].x);
-                            const float ny = add_unmerged(fy, (r & 1) ? termy[r / 2].y : termy[r / 2].x);
+                            const float nx = add_unmerged(fx, term_x(r));
+                            const float ny = add_unmerged(fy, term_y(r));
                             const bool skip = ((hits >> r) & 1u) != 0u;            // a collision adds no force term (not even +0)
                             fx = skip ? fx : nx;
                             fy = skip ? fy : ny;
@@ -1451,6 +1487,7 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         if (i >= lo && i < lo + cnt) Vown[i - lo] = vels[q];
         const bool bounded = abs_(r.x) < FastDomain<T>::coord && abs_(r.y) < FastDomain<T>::coord;
         bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
+        if (Jt != nullptr) bits |= coord_summary((float)r.x, (float)r.y) & kSummarySmall;     // fp32 contexts (ring kernel)
         const float ar = (float)abs_(r.r);
         rbits = (ar == ar) ? __float_as_uint(ar) : 0u;      // a NaN radius never collides (the predicate is false): skipped
     }
@@ -1472,7 +1509,8 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         }
     }
     const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
-                          (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0);
+                          (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0) |
+                          (__ballot(bits & kSummarySmall) != 0ull ? kSummarySmall : 0);
     if (wave_bits != 0 && (threadIdx.x & (kWave - 1)) == 0) atomicOr(&meta->summary, wave_bits);
     if (g == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         // every block has read meta-independent data only, so the in-place update is race-free
@@ -1564,8 +1602,7 @@ __global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData,
         const Rec<float> r{pi.x, pi.y, M[i], R[i]};
         J[i] = r;
         store_tiled(Jt, i, r);
-        const bool bounded = abs_(r.x) < FastDomain<float>::coord && abs_(r.y) < FastDomain<float>::coord;
-        bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
+        bits = coord_summary(r.x, r.y) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
         const float ar = abs_(r.r);
         rbits = (ar == ar) ? __float_as_uint(ar) : 0u;
     }
@@ -1574,7 +1611,8 @@ __global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData,
         rbits = o > rbits ? o : rbits;
     }
     const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
-                          (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0);
+                          (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0) |
+                          (__ballot(bits & kSummarySmall) != 0ull ? kSummarySmall : 0);
     if ((threadIdx.x & (kWave - 1)) == 0) {
         if (rbits != 0u) atomicMax(&tile_rmax[i / kTile], rbits);
         if (wave_bits != 0) atomicOr(&meta->summary, wave_bits);
