@@ -445,8 +445,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the guarded domain of the fast chains per precision: pairs with d2 <= fma(rs, rs, lo) or a coordinate at or beyond
 // `coord` (so d2 could exceed the upper edge) are left to the general code
 template <typename T> struct FastDomain;
-template <> struct FastDomain<float> { static constexpr float lo = kFastLo, coord = kCoordBound; };
-template <> struct FastDomain<double> { static constexpr double lo = 0x1p-500, coord = 0x1p249; };
+// `floor`: with both bodies' coordinates at or above it in magnitude a coordinate difference is 0 or at least one spacing of
+// the format there, so d2 is exactly 0 or above `lo` (fp32: 2^-39 squared = 2^-78; fp64: 2^-242 squared = 2^-484): with
+// all radii +0 the only pairs outside the fast domain are coincident bodies (see kCoordFloor)
+template <> struct FastDomain<float> { static constexpr float lo = kFastLo, coord = kCoordBound, floor = kCoordFloor; };
+template <> struct FastDomain<double> { static constexpr double lo = 0x1p-500, coord = 0x1p249, floor = 0x1p-190; };
 
 __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return __builtin_fabs(x); }
@@ -457,6 +460,12 @@ __device__ __forceinline__ unsigned long long le_mask(float a, float b) {     //
 }
 __device__ __forceinline__ unsigned long long le_mask(double a, double b) {
     return __builtin_amdgcn_fcmp(a, b, 5 /* llvm::CmpInst::FCMP_OLE */);
+}
+__device__ __forceinline__ unsigned long long unordered_mask(float a, float b) {   // wave mask of "a or b is NaN"
+    return __builtin_amdgcn_fcmpf(a, b, 8 /* llvm::CmpInst::FCMP_UNO */);
+}
+__device__ __forceinline__ unsigned long long unordered_mask(double a, double b) {
+    return __builtin_amdgcn_fcmp(a, b, 8 /* llvm::CmpInst::FCMP_UNO */);
 }
 __device__ __forceinline__ bool not_plus_zero(float x) { return __float_as_uint(x) != 0u; }
 __device__ __forceinline__ bool not_plus_zero(double x) { return __double_as_longlong(x) != 0ll; }
