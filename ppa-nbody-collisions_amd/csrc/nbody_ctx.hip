@@ -339,6 +339,8 @@ void launch_forces<float>(nbody_ctx* c, const StepParams<float>& p, int nblocks,
         case 52: launch_ring<4, 32, 8, false, 4>(c, p, nblocks, log, to); return;   // 4 rings of 4 waves per workgroup
         case 54: launch_ring<8, 32, 2, false, 1>(c, p, nblocks, log, to); return;   // one ring of 8 waves per workgroup
         case 53: launch_ring<8, 16, 8, false, 2>(c, p, nblocks, log, to); return;   // tuning: turns of 16 positions
+        case 55: launch_ring<8, 32, 2, false, 2>(c, p, nblocks, log, to); return;   // tuning: 2 x 8 with a 128-cycle poll interval
+        case 56: launch_ring<8, 32, 4, false, 2>(c, p, nblocks, log, to); return;   // tuning: 2 x 8 with a 256-cycle poll interval
         case 58: launch_ring<8, 32, 8, true, 2>(c, p, nblocks, log, to); return;    // tuning: in-kernel phase stamps
         default: break;
     }
