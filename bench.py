@@ -38,7 +38,7 @@ PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_pmc.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic_pmc.json")
 
 
 def measured_traffic(a, world):
