@@ -153,7 +153,7 @@ typedef struct nbody_ctx_desc {
     int kernel_variant;     /* 0 = automatic (by own-range size); tuning / A-B testing only: 1 general kernel,  */
                             /* 11/12/14/18 one-lane..eight-lanes-per-body kernel, 31/32 its 256-thread form,    */
                             /* 50/52/54 ring-of-waves kernel with 2x8 / 4x4 / 1x8 (rings x waves) workgroups    */
-                            /* (53, 58: its tuning forms).  fp64: 1 selects the general kernel, anything else   */
+                            /* (53, 55, 56, 58: its tuning forms).  fp64: 1 selects the general kernel, anything else */
                             /* the fp64 production kernel                                                       */
 } nbody_ctx_desc;
 

@@ -262,7 +262,7 @@ int read_meta(nbody_ctx* c) {
 // kernel_variant: 0 automatic | 1 v1 (one body per lane, compiler IEEE sqrt/div) |
 //                 11,12,14,18 v3 with K = 1,2,4,8 lanes per body, 128-thread workgroups |
 //                 31,32 v3 K = 1 with 256-thread workgroups, registers sized for 4 / 2 waves per SIMD |
-//                 50,52,54 ring of waves with 2x8, 4x4, 1x8 (rings x waves) per workgroup; 53,58 its tuning forms
+//                 50,52,54 ring of waves with 2x8, 4x4, 1x8 (rings x waves) per workgroup; 53,55,56,58 its tuning forms
 // Where a force launch goes: the context's own stream and velocities, or - the reference-shaped launch through the
 // workspace context - the caller's stream and the velocities where they lie in the caller's block.
 struct LaunchTarget {
@@ -1139,7 +1139,7 @@ const char* nbody_force_kernel_name(nbody_ctx* c) {
         case 1: return "forces_v1<float>";
         case 11: case 12: case 14: case 18: return "forces_v3_f32";
         case 31: case 32: return "forces_v3w_f32";
-        case 50: case 58: return "forces_ring_f32 (2 rings x 8 waves per workgroup)";
+        case 50: case 55: case 56: case 58: return "forces_ring_f32 (2 rings x 8 waves per workgroup)";
         case 52: return "forces_ring_f32 (4 rings x 4 waves per workgroup)";
         case 53: return "forces_ring_f32 (2 rings x 8 waves, 16-position turns)";
         case 54: return "forces_ring_f32 (1 ring x 8 waves per workgroup)";
