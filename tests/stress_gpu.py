@@ -15,7 +15,7 @@ import torch  # noqa: F401,E402
 import ppa_nbody_collisions_amd as nb  # noqa: E402
 import oracle_lib as ol  # noqa: E402
 
-VARIANTS = [0, 0, 50, 52, 53, 54, 31, 11]
+VARIANTS = [0, 0, 50, 52, 53, 54, 55, 31, 11]
 DT, GROWTH = np.float32(0.2), np.float32(0.1)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
@@ -30,7 +30,7 @@ while time.time() - t0 < budget:
     sem = int(rng.integers(0, 4) == 0)
     variant = int(rng.choice(VARIANTS))
     world = int(rng.choice([1, 1, 2, 3, 5, 8]))
-    steps = int(rng.integers(2, 7))
+    steps = int(rng.integers(2, 12))              # beyond 4 steps the slot layout follows the count four steps back
     log = bool(rng.integers(0, 3) == 0)             # the event-logging builds of the kernels, events checked too
     cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=min_r, maxRadius=max_r,
                           maxRandBodyMass=max_m)
