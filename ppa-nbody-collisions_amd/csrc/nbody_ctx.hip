@@ -684,7 +684,7 @@ int nbody_upload(nbody_ctx* c, const void* block, int n) {
             const bool bounded = fabsf(st[i].x) < FastDomain<float>::coord && fabsf(st[i].y) < FastDomain<float>::coord;
             const bool small = !(fabsf(st[i].x) >= kCoordFloor && fabsf(st[i].y) >= kCoordFloor);
             summary |= (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero_host(R[i]) ? kSummaryRadius : 0) |
-                       (small ? kSummarySmall : 0);
+                       (small ? kSummarySmall : 0) | (fabsf(st[i].m) < kMassBound ? 0 : kSummaryMass);
         }
         HIP_TRY(hipMemcpyAsync(c->J, st, (size_t)n * sizeof(Rec<float>), hipMemcpyHostToDevice, c->stream));
         if (n > 0) hipLaunchKernelGGL(records_to_tiles_f32, dim3((n + 255) / 256), dim3(256), 0, c->stream,

@@ -53,11 +53,12 @@ struct Meta {
     int step;     // step counter since upload
     int n_prev;   // body count before the last step's compaction (the reference renders with its block count)
     int summary;  // of the replica: bit 0 some coordinate is not below kCoordBound in magnitude (or NaN), bit 1 some
-                  // radius is not +0, bit 2 some coordinate is below kCoordFloor in magnitude (zero included).  OR-ed
-                  // together by unpack_slots (cleared by compact_count), set by nbody_upload.
+                  // radius is not +0, bit 2 some coordinate is below kCoordFloor in magnitude (zero included), bit 3 some
+                  // mass is not below kMassBound in magnitude (or NaN).  OR-ed together by unpack_slots (cleared by
+                  // compact_count), set by nbody_upload.
     int pad[2];
 };
-constexpr int kSummaryUnbounded = 1, kSummaryRadius = 2, kSummarySmall = 4;
+constexpr int kSummaryUnbounded = 1, kSummaryRadius = 2, kSummarySmall = 4, kSummaryMass = 8;
 
 struct Event { int32_t step, i, j, kind; };
 
@@ -306,10 +307,16 @@ constexpr float kCoordBound = 0x1p38f;     // |x|,|y| < 2^38 for both bodies  =>
 // collisions - are COINCIDENT bodies, and those turn their term into NaN (v_rsq_f32(0) = inf, 0 * inf = NaN): the ring
 // kernel then needs no screen per pair at all, it looks at the sum after the turn's adds (see its turn loop).
 constexpr float kCoordFloor = 0x1p-16f;
-__device__ __forceinline__ int coord_summary(float x, float y) {
+// That look at the sum also fires for a sum that is NaN for any other reason, and a lane whose sum is NaN takes the exact
+// path in every turn from then on: right, but slow.  A NaN or infinite mass would do that to every body at once, so the
+// NaN-sum screen is only used while every mass of the replica is finite and below 2^90 (a term then only overflows for
+// bodies closer than the coordinates' spacing allows at ordinary magnitudes).
+constexpr float kMassBound = 0x1p90f;
+__device__ __forceinline__ int coord_summary(float x, float y, float m) {
     const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
     return ((ax < kCoordBound && ay < kCoordBound) ? 0 : kSummaryUnbounded) |
-           ((ax >= kCoordFloor && ay >= kCoordFloor) ? 0 : kSummarySmall);
+           ((ax >= kCoordFloor && ay >= kCoordFloor) ? 0 : kSummarySmall) |
+           (__builtin_fabsf(m) < kMassBound ? 0 : kSummaryMass);
 }
 
 struct FastChain { float d, inv; };
@@ -808,8 +815,8 @@ void forces_ring_f32(const RingArgs args) {
     __shared__ Float4 hand_m_all[kRings][kWave];           // {mnew, rnew, mi, -}: rewritten only when mnew / rnew change
     const int N = meta->n, lo = meta->lo, cnt = meta->cnt;
     const bool all_bounded = (meta->summary & kSummaryUnbounded) == 0, any_radius = (meta->summary & kSummaryRadius) != 0;
-    // every coordinate of the replica in [2^-16, 2^38) and every radius +0: coincident bodies are the only pairs a fast
-    // turn must not add up, and they show as a NaN sum (kCoordFloor)
+    // every coordinate of the replica in [2^-16, 2^38), every radius +0, every mass finite: coincident bodies are the only
+    // pairs a fast turn must not add up, and they show as a NaN sum (kCoordFloor, kMassBound)
     const bool nan_screen = meta->summary == 0;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid / kWave);
@@ -1496,7 +1503,7 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
         if (i >= lo && i < lo + cnt) Vown[i - lo] = vels[q];
         const bool bounded = abs_(r.x) < FastDomain<T>::coord && abs_(r.y) < FastDomain<T>::coord;
         bits = (bounded ? 0 : kSummaryUnbounded) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
-        if (Jt != nullptr) bits |= coord_summary((float)r.x, (float)r.y) & kSummarySmall;     // fp32 contexts (ring kernel)
+        if (Jt != nullptr) bits |= coord_summary((float)r.x, (float)r.y, (float)r.m) & (kSummarySmall | kSummaryMass);   // fp32 contexts (ring kernel)
         const float ar = (float)abs_(r.r);
         rbits = (ar == ar) ? __float_as_uint(ar) : 0u;      // a NaN radius never collides (the predicate is false): skipped
     }
@@ -1519,7 +1526,8 @@ __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restr
     }
     const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
                           (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0) |
-                          (__ballot(bits & kSummarySmall) != 0ull ? kSummarySmall : 0);
+                          (__ballot(bits & kSummarySmall) != 0ull ? kSummarySmall : 0) |
+                          (__ballot(bits & kSummaryMass) != 0ull ? kSummaryMass : 0);
     if (wave_bits != 0 && (threadIdx.x & (kWave - 1)) == 0) atomicOr(&meta->summary, wave_bits);
     if (g == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         // every block has read meta-independent data only, so the in-place update is race-free
@@ -1611,7 +1619,7 @@ __global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData,
         const Rec<float> r{pi.x, pi.y, M[i], R[i]};
         J[i] = r;
         store_tiled(Jt, i, r);
-        bits = coord_summary(r.x, r.y) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
+        bits = coord_summary(r.x, r.y, r.m) | (not_plus_zero(r.r) ? kSummaryRadius : 0);
         const float ar = abs_(r.r);
         rbits = (ar == ar) ? __float_as_uint(ar) : 0u;
     }
@@ -1621,7 +1629,8 @@ __global__ __launch_bounds__(256) void ref_layout_pack_f32(const void* bodyData,
     }
     const int wave_bits = (__ballot(bits & kSummaryUnbounded) != 0ull ? kSummaryUnbounded : 0) |
                           (__ballot(bits & kSummaryRadius) != 0ull ? kSummaryRadius : 0) |
-                          (__ballot(bits & kSummarySmall) != 0ull ? kSummarySmall : 0);
+                          (__ballot(bits & kSummarySmall) != 0ull ? kSummarySmall : 0) |
+                          (__ballot(bits & kSummaryMass) != 0ull ? kSummaryMass : 0);
     if ((threadIdx.x & (kWave - 1)) == 0) {
         if (rbits != 0u) atomicMax(&tile_rmax[i / kTile], rbits);
         if (wave_bits != 0) atomicOr(&meta->summary, wave_bits);

@@ -379,6 +379,45 @@ def test_coincident_bodies_at_zero_radii(nb, variant, precision, small):
 
 
 @pytest.mark.parametrize("variant", [0, 50, 52, 54, 31])
+@pytest.mark.parametrize("masses", ["finite", "non-finite"])
+def test_non_finite_sums_under_the_nan_screen(nb, variant, masses):
+    """The NaN-sum screen (all radii +0, all coordinates in [2^-16, 2^38), all masses below 2^90) flags a lane whenever its
+    running sum is NaN.  `finite`: three heavy bodies (2^89) one float spacing apart make terms overflow - +inf from one
+    side, -inf from the other, NaN sums for them and inf for their neighbours in the walk - with every mass finite, so the
+    screen stays on and those lanes take the exact path in every later turn (slow, and it must still be right); a coincident
+    pair sits among them.  `non-finite`: a NaN and two infinite masses switch the launch back to the per-pair screen
+    (Meta::summary bit 3): same oracle.  NaN payloads differ between x86 and gfx950: NaNs compare equal to NaNs."""
+    n = 2048
+    cfg = nb.stock_config(particleCount=n, minRadius=0.0, maxRadius=0.0)
+    bodies = nb.init_bodies(cfg)
+    P, M = bodies.Positions, bodies.Masses
+    if masses == "finite":
+        one = np.float32(1.0)
+        P[600] = [np.nextafter(one, np.float32(0)), 3.0]
+        P[601] = [one, 3.0]
+        P[1300] = [np.nextafter(one, np.float32(2)), 3.0]
+        M[600] = M[601] = M[1300] = np.float32(2.0 ** 89)
+    else:
+        M[700] = np.nan
+        M[1500] = np.inf
+        M[1501] = -np.inf
+    P[900] = P[40]
+    st = nb.Stepper(cfg, kernel_variant=variant)
+    st.upload(bodies)
+    blk = bodies.contiguousData.copy()
+    cur = n
+    for s in range(3):
+        st.step(1)
+        cur, *_ = ol.port_step(blk, cur, DT, 100000, 100000, GROWTH, want_events=False)
+        out = st.download()
+        assert out.numBodies == cur, "step %d" % s
+        assert _nan_aware_equal(out.block, blk[:6 * cur]), "step %d" % s
+    if masses == "finite":
+        assert not np.isfinite(blk[:6 * cur]).all(), "the case is meant to produce non-finite state"
+    st.close()
+
+
+@pytest.mark.parametrize("variant", [0, 50, 52, 54, 31])
 @pytest.mark.parametrize("n", [3000, 4096])
 def test_collision_screen_radius_bounds(nb, variant, n):
     """The ring kernel screens a turn for collisions with ONE threshold per lane, fma(R, R, 2^-80), R = |ri| + the largest
