@@ -5,9 +5,12 @@ and bench.py's parity leg for RCCL).  What IS product code here: the partition r
 
 The device code shards a step as: rank g owns a contiguous, block-aligned global range [lo_g, lo_g+cnt_g)
 (nbody_partition); it computes the post-step state of its range (reading the full replica), compacts its survivors
-into a fixed-size slot {count, records, velocities}, the slots are all-gathered, and every rank rebuilds the replica
+into a slot {count, records, velocities}, the slots are all-gathered, and every rank rebuilds the replica
 in rank order and RE-DRAWS the partition from the survivor count, taking the velocities of its new range from the
-slots (csrc/nbody_kernels.hpp: compact_scatter, unpack_slots; csrc/nbody_partition.h: nbody_own_range_of; csrc/nbody_ctx.hip: nbody_step).  This
+slots (csrc/nbody_kernels.hpp: compact_scatter, unpack_slots; csrc/nbody_partition.h: nbody_own_range_of; csrc/nbody_ctx.hip: nbody_step).
+The slots are laid out for U = own_upper_of(n*) bodies, where n* is the body count FOUR STEPS BACK (the uploaded count
+before that): the one bound every rank derives identically without looking at the current step (csrc/nbody_ctx.hip:
+refresh_bound, slot_bodies); the all-gather moves that many rows, not the capacity.  This
 file runs that protocol over torch.distributed with the CPU oracle doing the per-range arithmetic (the oracle is the
 checker here, not a product path) and checks it against the single-rank oracle bit for bit - including deletions,
 ranges that move between ranks, and the index-dependent literal semantics, which depend on GLOBAL indices and the
@@ -43,7 +46,13 @@ def _rank_main(rank, world, port, n0, field, steps, q):
     J = np.concatenate([P, M[:, None], R[:, None]], axis=1)          # replica {x,y,m,r}
     Vown = V[lo:lo + cnt].copy()
     moved = 0
+    lag = 4                                                           # nbody_ctx::kLag
+    history = []                                                      # body count after each step
+    rows_moved = 0
     for s in range(steps):
+        n_star = n0 if s < lag else history[s - lag]                  # refresh_bound: the count four steps back
+        upper = ((n_star + 127) // 128 + world - 1) // world * 128    # slot_bodies = nbody_own_upper_of(n*, world)
+        assert n <= n_star and cnt <= upper
         # compute phase on the own range, from the replica + own velocities
         blk = np.empty(6 * n, np.float32)
         p_, v_, m_, r_ = ol.carve(blk, n)
@@ -52,13 +61,15 @@ def _rank_main(rank, world, port, n0, field, steps, q):
         v_[lo:lo + cnt] = Vown
         oP, oV, oM, oR, _, _ = ol.port_range(blk, n, lo, lo + cnt, dt, field, field, growth)
         keep = oM != 0                                                # src/nbody.cu:488-510
-        slot = np.zeros((cap_own + 1, 6), np.float32)                 # row 0: header; then {x,y,m,r,vx,vy}
+        slot = np.zeros((upper + 1, 6), np.float32)                   # row 0: header; then {x,y,m,r,vx,vy}
         c = int(keep.sum())
+        assert c <= upper
         slot[0, 0] = c
         slot[1:1 + c] = np.concatenate([oP[keep], oM[keep, None], oR[keep, None], oV[keep]], axis=1)
         # exchange phase
-        gathered = [torch.zeros(cap_own + 1, 6) for _ in range(world)]
+        gathered = [torch.zeros(upper + 1, 6) for _ in range(world)]  # a rank with another `upper` would fail here
         dist.all_gather(gathered, torch.from_numpy(slot))
+        rows_moved += world * (upper + 1)
         # commit phase: replica in rank order, partition re-drawn from the survivor count, own velocities from the slots
         counts = [int(g[0, 0]) for g in gathered]
         allrec = np.concatenate([g.numpy()[1:1 + k] for g, k in zip(gathered, counts)], axis=0)
@@ -69,6 +80,7 @@ def _rank_main(rank, world, port, n0, field, steps, q):
         moved += int(lo != old_lo or cnt != counts[rank])
         assert cnt <= cap_own and lo % 128 == 0
         Vown = allrec[lo:lo + cnt, 4:6].copy()
+        history.append(n)
     # assemble the full state on rank 0 (velocities by padded gather, like nbody_download)
     vbuf = np.zeros((cap_own, 2), np.float32)
     vbuf[:cnt] = Vown
@@ -79,7 +91,7 @@ def _rank_main(rank, world, port, n0, field, steps, q):
     if rank == 0:
         Vall = np.concatenate([v.numpy()[:int(k)] for v, k in zip(vg, cg)], axis=0)
         out = ol.make_block(J[:, :2], Vall, J[:, 2], J[:, 3])
-        q.put((n, out.view(np.uint32).copy(), moved))
+        q.put((n, out.view(np.uint32).copy(), moved, rows_moved, steps * world * (cap_own + 1)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -115,7 +127,7 @@ def test_sharded_protocol_equals_single_rank(world, n0, field, steps):
     procs = [ctx.Process(target=_rank_main, args=(r, world, port, n0, field, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    n_got, blk_got, moved = q.get(timeout=240)
+    n_got, blk_got, moved, rows_moved, rows_at_capacity = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -129,3 +141,5 @@ def test_sharded_protocol_equals_single_rank(world, n0, field, steps):
     if field <= 5000:
         assert n < n0          # the case really exercises deletions ...
         assert moved > 0       # ... and bodies changing hands when the partition is re-drawn
+    if steps > 8 and field <= 5000:
+        assert rows_moved < rows_at_capacity   # ... and the exchange shrinking with the count (four steps late)
