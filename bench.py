@@ -89,8 +89,22 @@ def cpu_topology():
         usable = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         usable = logical
+    # the CPU-time quota of the container (cgroup v2 cpu.max / v1 cfs quota), in cores: what the OpenMP threads SHARE
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
     return {"sockets": len(sockets) or None, "physical_cores": len(cores) or None, "logical_cpus": logical or None,
-            "cpus_usable_by_this_process": usable}
+            "cpus_usable_by_this_process": usable, "cpu_quota_cores": quota}
 
 
 def cpu_baseline(nb, bodies, cfg, budget_s=12.0, semantics=0):
@@ -101,12 +115,17 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0, semantics=0):
     import numpy as np
     import oracle_lib as ol
     n = bodies.numBodies
+    topo = cpu_topology()
     threads = ol.port().oracle_get_max_threads()
+    if topo["cpu_quota_cores"] and topo["cpu_quota_cores"] < threads:
+        # more threads than the container's CPU quota only time-share the same cores: use (and report) the quota
+        threads = max(1, int(round(topo["cpu_quota_cores"])))
+        ol.port().oracle_set_threads(threads)
     blk = bodies.contiguousData
     dt, gr = np.float32(cfg.timestep), np.float32(cfg.growthRate)
     if bodies.precision == nb.F64:
         dt, gr = float(dt), float(gr)
-    probe = min(n, 4 * threads)
+    probe = min(n, 32 * threads)
     t0 = time.perf_counter()
     *_, st = ol.port_range(blk, n, 0, probe, dt, cfg.fieldWidth, cfg.fieldHeight, gr, semantics=semantics)
     t_probe = time.perf_counter() - t0
@@ -120,12 +139,12 @@ def cpu_baseline(nb, bodies, cfg, budget_s=12.0, semantics=0):
     oP, oV, oM, oR, _, st = ol.port_range(blk, n, lo, lo + count, dt, cfg.fieldWidth, cfg.fieldHeight, gr,
                                           semantics=semantics)
     t = time.perf_counter() - t0
-    topo = cpu_topology()
     base = {"value": st.pairs / t, "unit": "body-pair-interactions/sec", "cores": threads, "kind": "port",
             "cpu_model": cpu_model(), "cpu_topology": topo,
             "cores_note": "`cores` = OpenMP threads used; the host has %s socket(s), %s physical cores, %s logical CPUs, "
-                          "%s usable by this process" % (topo["sockets"], topo["physical_cores"], topo["logical_cpus"],
-                                                         topo["cpus_usable_by_this_process"]),
+                          "%s usable by this process, CPU quota of the container: %s cores" %
+                          (topo["sockets"], topo["physical_cores"], topo["logical_cpus"],
+                           topo["cpus_usable_by_this_process"], topo["cpu_quota_cores"]),
             "sample": "bodies [%d,%d) of step 1 at N=%d against all j (%d pairs, %.1f s, OpenMP %d threads)" %
                       (lo, lo + count, n, st.pairs, t, threads)}
     # the same restatement on ONE thread, about two seconds of it
