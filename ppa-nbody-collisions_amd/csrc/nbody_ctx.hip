@@ -319,6 +319,12 @@ void launch_ring(nbody_ctx* c, const StepParams<float>& p, int nblocks, bool log
     a.Vown = (const Vec2<float>*)to.vown; a.S_J = (Rec<float>*)c->S_J; a.S_V = (Vec2<float>*)c->S_V;
     a.meta = c->meta; a.p = p; a.ev = c->events; a.ev_cap = c->ev_cap; a.ctr = c->counters;
     a.tile_rmax = (const float*)c->tile_rmax; a.Jt = c->Jt; a.cap_own = c->cap_own; a.n_tiles = c->n_tiles;
+    // testing aid: make the index checks fire (the kernel is told the tiled copy is one tile long / the staging arrays hold
+    // one body), to see them reported instead of trusted
+    if (const char* e = getenv("NBODY_TEST_INDEX_CHECKS")) {
+        if (e[0] == 't') a.n_tiles = 1;
+        if (e[0] == 'q') a.cap_own = 1;
+    }
     if (log) hipLaunchKernelGGL((forces_ring_f32<true, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, to.stream, a);
     else hipLaunchKernelGGL((forces_ring_f32<false, kW, kT, kSleep, kProbe, kRings>), dim3(grid), dim3(kRings * kW * kWave), 0, to.stream, a);
 }

@@ -81,6 +81,34 @@ def test_ring_handoff_timeout_is_loud(nb, monkeypatch):
     ok.close(); one.close()
 
 
+@pytest.mark.parametrize("what,log", [("t", True), ("q", True), ("q", False)])
+def test_failed_index_check_is_reported_not_trusted(nb, monkeypatch, what, log):
+    """The ring kernel checks the indices it forms itself (the staging index of the epilogue in every build; in the
+    event-logging builds also the source range of every window gather and the radius-bound lookups).  Told - by a testing
+    aid - that the tiled copy is one tile long (`t`) or that the staging arrays hold one body (`q`), the checks fail: the
+    accesses are skipped, nothing faults, and every host call that looks at the device returns NBODY_ERR_HIP naming
+    the failed checks (CUDA_SYNC_CHECK's role, src/nbody.cu:20-33) until the next upload."""
+    cfg = nb.stock_config(particleCount=4096, fieldWidth=20000, fieldHeight=20000)
+    bodies = nb.init_bodies(cfg)
+    st = nb.Stepper(cfg, record_events=log)
+    st.upload(bodies)
+    monkeypatch.setenv("NBODY_TEST_INDEX_CHECKS", what)
+    st.step(1)
+    monkeypatch.delenv("NBODY_TEST_INDEX_CHECKS")
+    for call in (st.sync, st.download, lambda: st.step(1)):
+        with pytest.raises(nb.NbodyError) as e:
+            call()
+        assert e.value.status == -6 and "index check" in str(e.value) and " 0 failed index" not in str(e.value), str(e.value)
+    st.upload(bodies)                                  # a fresh upload clears it
+    st.step(2)
+    one = nb.Stepper(cfg, kernel_variant=31)
+    one.upload(bodies)
+    one.step(2)
+    a, b = st.download(), one.download()
+    assert a.numBodies == b.numBodies and np.array_equal(bits(a.block), bits(b.block))
+    st.close(); one.close()
+
+
 def test_fp64_fast_chain_against_ieee(nb):
     """2^32 inputs of each of three families of the guarded domain: the fp64 force kernel's sqrt / 1/d^3 chain
     gives the bits of the compiler's correctly-rounded sqrt and divide (not exhaustive: fp64 cannot be)."""
