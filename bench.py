@@ -203,25 +203,31 @@ def reference_kernels_on_gpu(nb, bodies, cfg, our_ms_per_step, steps=2):
     """The reference's OWN kernels on this GPU, as a baseline next to the CPU one: oracle/_ref/libnbody_ref_hip.so is the
     reference's device code (src/nbody.cu:126-292) compiled unmodified by hipcc for gfx950 (oracle/ref_hip, built where
     /root/reference exists) and launched with the reference's geometry.  Timed: ComputeForces + MoveBodies with HIP
-    events, i.e. WITHOUT the reference loop's per-step cudaMalloc / PCIe round trip / host compaction.  fp32 only (the
-    reference has no fp64 kernel).  Checker / baseline only, after the timed region; absent library -> None."""
+    events, i.e. WITHOUT the reference loop's per-step cudaMalloc / PCIe round trip / host compaction.  fp64 runs use the
+    fp64 reading of the same text (the reference has no fp64 kernel).  Checker / baseline only, after the timed region;
+    absent library -> None."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as ol
-    if bodies.precision != nb.F32 or not ol.have_ref_hip():
+    f64 = bodies.precision == nb.F64
+    if not (ol.have_ref_hip_f64() if f64 else ol.have_ref_hip()):
         return None
     n = bodies.numBodies
     blk = bodies.contiguousData.copy()
     pairs = 0
     cur = n
     total_ms = 0.0
+    dt, gr = np.float32(cfg.timestep), np.float32(cfg.growthRate)
+    if f64:
+        dt, gr = float(dt), float(gr)
     for _ in range(steps):
         pairs += ol.port().oracle_pairs_per_step(cur, ol.LITERAL)
-        cur, ms, _ = ol.ref_hip_run(blk, cur, 1, np.float32(cfg.timestep), cfg.fieldWidth, cfg.fieldHeight,
-                                    np.float32(cfg.growthRate))
+        cur, ms, _ = ol.ref_hip_run(blk, cur, 1, dt, cfg.fieldWidth, cfg.fieldHeight, gr)
         total_ms += ms
-    return {"what": "the reference's ComputeForces + MoveBodies (src/nbody.cu:139-292), compiled unmodified by hipcc "
-                    "-O3 for gfx950, its own launch geometry, kernel time only, first %d steps of this workload" % steps,
+    return {"what": "the reference's ComputeForces + MoveBodies (src/nbody.cu:139-292)%s, compiled by hipcc "
+                    "-O3 for gfx950, its own launch geometry, kernel time only, first %d steps of this workload" %
+                    (" with `float` read as `double` (the reference has no fp64 code: oracle/ref_hip, REF_FLOAT_AS_DOUBLE)"
+                     if f64 else ", unmodified", steps),
             "ms_per_step": total_ms / steps, "value": pairs / (total_ms * 1e-3), "unit": "body-pair-interactions/sec",
             "this_framework_ms_per_step": our_ms_per_step, "speedup": (total_ms / steps) / our_ms_per_step}
 

@@ -14,7 +14,9 @@
  * to the product up to N = 262144), and oracle/_ref/libnbody_ref.so runs the same text on the CPU behind a shim for the
  * CUDA execution model (oracle/ref_shim; generated tests/golden/; bit-identical too).  The FP model (no contraction) is
  * our choice; the other plausible one (default FMA contraction) is bounded: <= 4.3e-7 per step, identical collision
- * outcomes.  The fp64 variant has no reference at all (the reference has no fp64 kernel): parity unpinned for fp64.
+ * outcomes.  The fp64 variant: the reference has no fp64 code; the pin is the reference's own kernel text with `float` read
+ * as `double` (oracle/_ref/libnbody_ref_hip_f64.so, one macro in oracle/ref_hip), run on the GPU: bit-identical to the fp64
+ * instantiation of this file and to the product up to N = 1048576 (tests/test_gpu_reference_kernels.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */

@@ -14,17 +14,40 @@
 // written operation: the oracle of record's FP model) and hipcc's default contraction (what `nvcc -O3`, cudaCmd.txt:1,
 // also does by default: the FMA reading).
 //
+// A third build, REF_FLOAT_AS_DOUBLE (libnbody_ref_hip_f64.so): the fp64 READING of the same text.  The reference has no
+// fp64 code at all (its templated include/vec2.h is never included, src/nbody.cu:15), yet BASELINE.json's fifth
+// configuration is an fp64 stepper.  The closest thing to "the reference in fp64" that can exist without writing one is
+// its own kernel text and its own Vec2f header with the token `float` read as `double` - ONE macro around the two
+// #includes below, nothing else touched: every variable, array element, kernel parameter and Vec2f member becomes a
+// double, sqrt() resolves to the double overload, and the float LITERALS of the text (GRAV_CONSTANT 6.67408e-11f,
+// `1.0f / val` in vec2f.h:52) stay float literals and are widened where they are used - exactly the convention the product's
+// fp64 path and the CPU oracle's fp64 instantiation follow.  System headers are included before the macro
+// is defined.  This is an fp64 pin that does not pass through any line of the product or of oracle/nbody_oracle.c.
+//
 // Used by tests/test_gpu_reference_kernels.py (parity of the product against the reference's kernels at full size, on
 // the GPU) and by bench.py's optional reference-timing leg.  Only tests/ and bench.py may load this library.
 #include <hip/hip_runtime.h>
+#include <assert.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cmath>
 #include <vector>
 
+#ifdef REF_FLOAT_AS_DOUBLE
+#define float double
+#endif
 #include "vec2f.h"
 
 #include REF_SLICE   // /root/reference/src/nbody.cu lines 35-37 and 126-292, verbatim, from a temp file
+#ifdef REF_FLOAT_AS_DOUBLE
+#undef float
+typedef double ref_real;
+#else
+typedef float ref_real;
+#endif
+static_assert(sizeof(Vec2f) == 2 * sizeof(ref_real), "Vec2f holds two reals of the build's precision");
 
 namespace {
 thread_local char g_err[256];
@@ -44,30 +67,32 @@ extern "C" const char* refhip_last_error(void) { return g_err; }
 // The block is updated in place and re-carved for the survivors after every step; *n becomes the survivor count.
 // pre_compaction (optional, 24 * n_at_last_step bytes): the block after the last step's kernels, before its compaction.
 // kernel_ms (optional): sum over the steps of the time of ComputeForces + MoveBodies measured with HIP events.
-extern "C" int refhip_run(void* host_block, int* n_io, int steps, float timestep, int fieldWidth, int fieldHeight,
-                          float growthRate, void* pre_compaction, double* kernel_ms) {
+// (fp64 build: the block holds doubles, 48 bytes per body; timestep and growthRate are doubles.)
+extern "C" int refhip_real_bytes(void) { return (int)sizeof(ref_real); }
+extern "C" int refhip_run(void* host_block, int* n_io, int steps, ref_real timestep, int fieldWidth, int fieldHeight,
+                          ref_real growthRate, void* pre_compaction, double* kernel_ms) {
     if (!host_block || !n_io || *n_io < 0 || steps < 0) return -2;
     int numBodies = *n_io;
-    float* block = (float*)host_block;
+    ref_real* block = (ref_real*)host_block;
     const int threadsPerBlock = THREADS_PER_BLOCK;                                              // :445
     const size_t sharedMemSize =
-        threadsPerBlock * ((2 * (sizeof(Vec2f) + sizeof(float) + sizeof(float))) + 2 * sizeof(Vec2f));   // :451
+        threadsPerBlock * ((2 * (sizeof(Vec2f) + sizeof(ref_real) + sizeof(ref_real))) + 2 * sizeof(Vec2f));   // :451
     hipEvent_t e0, e1;
     RH_TRY(hipEventCreate(&e0));
     RH_TRY(hipEventCreate(&e1));
     double total_ms = 0.0;
     for (int iteration = 0; iteration < steps && numBodies > 0; ++iteration) {
-        const size_t bytes = (size_t)numBodies * 24;                                            // :66
+        const size_t bytes = (size_t)numBodies * 6 * sizeof(ref_real);                          // :66
         void* d_block = nullptr;
-        float *d_updatedMasses = nullptr, *d_updatedRadii = nullptr;
+        ref_real *d_updatedMasses = nullptr, *d_updatedRadii = nullptr;
         RH_TRY(hipMalloc(&d_block, bytes));                                                     // :93
-        RH_TRY(hipMalloc((void**)&d_updatedMasses, numBodies * sizeof(float)));                 // :463
-        RH_TRY(hipMalloc((void**)&d_updatedRadii, numBodies * sizeof(float)));                  // :464
+        RH_TRY(hipMalloc((void**)&d_updatedMasses, numBodies * sizeof(ref_real)));              // :463
+        RH_TRY(hipMalloc((void**)&d_updatedRadii, numBodies * sizeof(ref_real)));               // :464
         const int blocks = numBodies < threadsPerBlock ? 1 : numBodies / threadsPerBlock;       // :473
         RH_TRY(hipMemcpy(d_block, block, bytes, hipMemcpyHostToDevice));                        // :94
         // :467-470,477-478: the scratch arrays start as copies of the masses and radii
-        RH_TRY(hipMemcpy(d_updatedMasses, block + 4 * (size_t)numBodies, numBodies * sizeof(float), hipMemcpyHostToDevice));
-        RH_TRY(hipMemcpy(d_updatedRadii, block + 5 * (size_t)numBodies, numBodies * sizeof(float), hipMemcpyHostToDevice));
+        RH_TRY(hipMemcpy(d_updatedMasses, block + 4 * (size_t)numBodies, numBodies * sizeof(ref_real), hipMemcpyHostToDevice));
+        RH_TRY(hipMemcpy(d_updatedRadii, block + 5 * (size_t)numBodies, numBodies * sizeof(ref_real), hipMemcpyHostToDevice));
         RH_TRY(hipEventRecord(e0, 0));
         ComputeForces<<<blocks, threadsPerBlock, sharedMemSize, 0>>>(d_block, d_updatedMasses, (Vec2f*)nullptr, d_updatedRadii,
                                                                       numBodies, timestep, fieldWidth, fieldHeight, blocks,
@@ -83,13 +108,13 @@ extern "C" int refhip_run(void* host_block, int* n_io, int steps, float timestep
         hipFree(d_block); hipFree(d_updatedMasses); hipFree(d_updatedRadii);                    // :84,541-542
         if (pre_compaction && iteration == steps - 1) memcpy(pre_compaction, block, bytes);
         // :488-510 stable compaction on mass != 0, block re-carved for the new count
-        const float* M = block + 4 * (size_t)numBodies;
+        const ref_real* M = block + 4 * (size_t)numBodies;
         int newN = 0;
         for (int i = 0; i < numBodies; ++i) newN += M[i] != 0.f;
         if (newN != numBodies) {
-            std::vector<float> nb_((size_t)newN * 6);
-            float *nP = nb_.data(), *nV = nP + 2 * (size_t)newN, *nM = nV + 2 * (size_t)newN, *nR = nM + newN;
-            const float *P = block, *V = P + 2 * (size_t)numBodies, *R = M + numBodies;
+            std::vector<ref_real> nb_((size_t)newN * 6);
+            ref_real *nP = nb_.data(), *nV = nP + 2 * (size_t)newN, *nM = nV + 2 * (size_t)newN, *nR = nM + newN;
+            const ref_real *P = block, *V = P + 2 * (size_t)numBodies, *R = M + numBodies;
             int k = 0;
             for (int i = 0; i < numBodies; ++i)
                 if (M[i] != 0.f) {
@@ -98,7 +123,7 @@ extern "C" int refhip_run(void* host_block, int* n_io, int steps, float timestep
                     nM[k] = M[i]; nR[k] = R[i];
                     ++k;
                 }
-            memcpy(block, nb_.data(), (size_t)newN * 24);
+            memcpy(block, nb_.data(), (size_t)newN * 6 * sizeof(ref_real));
             numBodies = newN;
         }
     }

@@ -74,21 +74,33 @@ def have_ref_hip():
     return os.path.exists(REF_HIP_SO) and os.path.exists(REF_HIP_FMA_SO)
 
 
+REF_HIP_F64_SO = os.path.join(ROOT, "oracle", "_ref", "libnbody_ref_hip_f64.so")  # ... `float` read as `double`, no contraction
+
+
+def have_ref_hip_f64():
+    return os.path.exists(REF_HIP_F64_SO)
+
+
 def ref_hip_run(block, n, steps, dt, fw, fh, growth, fma=False, pre=False):
-    """`steps` iterations of the reference's own kernels ON THE GPU (oracle/ref_hip).  block: float32[>= 6n], updated in
-    place.  Returns (new_n, kernel_ms_total, pre_compaction_block_of_last_step | None)."""
-    path = REF_HIP_FMA_SO if fma else REF_HIP_SO
+    """`steps` iterations of the reference's own kernels ON THE GPU (oracle/ref_hip).  block: float32[>= 6n] - or float64
+    for the fp64 reading of the reference's text (libnbody_ref_hip_f64.so) -, updated in place.
+    Returns (new_n, kernel_ms_total, pre_compaction_block_of_last_step | None)."""
+    f64 = block.dtype == np.float64
+    assert not (f64 and fma)
+    path = REF_HIP_F64_SO if f64 else (REF_HIP_FMA_SO if fma else REF_HIP_SO)
+    real = ctypes.c_double if f64 else ctypes.c_float
     if path not in _ref_hip:
         L = ctypes.CDLL(path)
-        L.refhip_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_float,
-                                 ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+        L.refhip_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, real,
+                                 ctypes.c_int, ctypes.c_int, real, ctypes.c_void_p,
                                  ctypes.POINTER(ctypes.c_double)]
         L.refhip_last_error.restype = ctypes.c_char_p
+        assert L.refhip_real_bytes() == (8 if f64 else 4)
         _ref_hip[path] = L
     L = _ref_hip[path]
     cn = ctypes.c_int(n)
     ms = ctypes.c_double(0.0)
-    preb = np.empty(6 * n, dtype=np.float32) if pre else None
+    preb = np.empty(6 * n, dtype=block.dtype) if pre else None
     rc = L.refhip_run(block.ctypes.data, ctypes.byref(cn), steps, dt, fw, fh, growth,
                       preb.ctypes.data if pre else None, ctypes.byref(ms))
     if rc != 0:

@@ -1096,9 +1096,9 @@ def test_error_paths(nb):
 @pytest.mark.parametrize("variant", [0, 1], ids=["production-kernel", "general-kernel"])
 @pytest.mark.parametrize("n,field,max_r", [(1500, 6000, 200.0), (4096, 100000, 200.0), (5000, 100000, 0.0)])
 def test_fp64_matches_oracle(nb, n, field, max_r, variant):
-    """fp64 twin (configs[4] shape, small): no reference exists for fp64 ('parity unpinned'); both fp64 kernels
-    (fast chain / compiler IEEE sqrt and divide) are checked bit-exactly against the fp64 instantiation of the
-    oracle, with events, dense and sparse, with and without radii."""
+    """fp64 twin (configs[4] shape, small): both fp64 kernels (fast chain / compiler IEEE sqrt and divide) bit-exactly
+    against the fp64 instantiation of the oracle, with events, dense and sparse, with and without radii.  (The reference
+    has no fp64 code; what pins fp64 is its kernel text read at double precision: test_gpu_reference_kernels.py.)"""
     cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=0.0, maxRadius=max_r)
     bodies = nb.init_bodies(cfg, nb.F64)
     st = nb.Stepper(cfg, precision=nb.F64, kernel_variant=variant, record_events=True)

@@ -91,6 +91,36 @@ def test_c4_whole_horizon_equals_reference_kernels(nb, radii, chunk):
           (radii, n, cur, chunk, ref_ms / 1e3, ours_ms / 1e3))
 
 
+@pytest.mark.skipif(not ol.have_ref_hip_f64(), reason="oracle/_ref/libnbody_ref_hip_f64.so not built")
+@pytest.mark.parametrize("n,field,radii,steps,variant", [
+    (1000, 5000, "stock", 40, 0),        # dense, ragged, frozen tail
+    (1, 3000, "stock", 3, 0), (2, 3000, "stock", 8, 0), (127, 3000, "stock", 8, 0), (128, 3000, "stock", 8, 0),
+    (129, 3000, "stock", 8, 0), (130, 3000, "stock", 8, 0), (200, 3000, "stock", 8, 0), (257, 3000, "stock", 8, 0),
+    (4096, 20000, "stock", 30, 0), (4096, 20000, "stock", 30, 1),      # production and general fp64 kernel
+    (65536, 100000, "r0", 40, 0),
+    (65536, 100000, "stock", 100, 0),    # the count collapses
+    (262144, 100000, "r0", 4, 0),
+    (1048576, 100000, "r0", 2, 0),       # C5 (BASELINE configs[4]) at full size: two steps of the reference's text at fp64
+])
+def test_fp64_product_equals_reference_text_read_as_double(nb, n, field, radii, steps, variant):
+    """The fp64 path against the only "reference in fp64" there can be: the reference's own kernel text and Vec2f header
+    with `float` read as `double` (oracle/ref_hip, REF_FLOAT_AS_DOUBLE: one macro, nothing else touched, float literals
+    widened where they are used), compiled by hipcc without contraction and run on the same GPU.  Free-running from the
+    reference's initial condition with the double draws kept (include/jbutil.h:554-561), whole state, bit for bit.
+    This pin passes through no line of the product and no line of our CPU restatement."""
+    kw = {"minRadius": 0.0, "maxRadius": 0.0} if radii == "r0" else {}
+    cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, **kw)
+    bodies = nb.init_bodies(cfg, nb.F64)
+    blk = bodies.contiguousData.copy()
+    n_ref, ms, _ = ol.ref_hip_run(blk, n, steps, float(DT), field, field, float(GROWTH))
+    out = _product(nb, cfg, bodies, steps, precision=nb.F64, kernel_variant=variant)
+    assert out.numBodies == n_ref
+    assert np.array_equal(out.block.view(np.uint64), blk[:6 * n_ref].view(np.uint64)), \
+        "fp64 product != reference text at double precision after %d steps" % steps
+    print("\nfp64 N=%d %s: %d steps, %d -> %d bodies; reference text at double precision %.2f ms per step on this GPU" %
+          (n, radii, steps, n, n_ref, ms / steps))
+
+
 def test_reference_kernels_equal_cpu_oracle(nb):
     """The same kernels against the CPU restatement (the oracle every other test uses), incl. pre-compaction state."""
     for n, field in ((1000, 5000), (4096, 100000)):

@@ -126,7 +126,8 @@ def _dense(n, seed=3):
 
 
 def test_f64_step_consistency():
-    """fp64 has no reference (parity unpinned); check it agrees with fp32 to fp32 accuracy on a short run."""
+    """The fp64 instantiation agrees with fp32 to fp32 accuracy on a short run (its bit-level pin is on the GPU: the
+    reference's kernel text read at double precision, tests/test_gpu_reference_kernels.py)."""
     P, V, M, R = _dense(300)
     b32 = ol.make_block(P, V, M, R, np.float32)
     b64 = ol.make_block(P, V, M, R, np.float64)
