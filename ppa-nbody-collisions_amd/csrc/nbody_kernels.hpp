@@ -1124,11 +1124,18 @@ void forces_ring_f32(const RingArgs args) {
             const float reach = abs_(ri) + cur.rmax;
             const float threshold = __builtin_fmaf(reach, reach, kFastLo);
             float closest = kFastHi;
+            // the reads of a batch are issued one batch ahead (NB_RING_PREFETCH): their latency then runs under the arithmetic
+            // of the batch before instead of being exposed at every batch's start
+            V2 pxa = {wx[0], wx[1]}, pxb = {wx[2], wx[3]}, pya = {wy[0], wy[1]}, pyb = {wy[2], wy[3]};
+            V2 pma = {wm[0], wm[1]}, pmb = {wm[2], wm[3]};
 #pragma unroll
             for (int r0 = 0; r0 < kT; r0 += 4) {           // four walk positions per batch of reads: a, a, b, b
-                const V2 xa = {wx[r0], wx[r0 + 1]}, xb = {wx[r0 + 2], wx[r0 + 3]};
-                const V2 ya = {wy[r0], wy[r0 + 1]}, yb = {wy[r0 + 2], wy[r0 + 3]};
-                const V2 ma = {wm[r0], wm[r0 + 1]}, mb = {wm[r0 + 2], wm[r0 + 3]};
+                const V2 xa = pxa, xb = pxb, ya = pya, yb = pyb, ma = pma, mb = pmb;
+                if (r0 + 4 < kT) {
+                    pxa = V2{wx[r0 + 4], wx[r0 + 5]}; pxb = V2{wx[r0 + 6], wx[r0 + 7]};
+                    pya = V2{wy[r0 + 4], wy[r0 + 5]}; pyb = V2{wy[r0 + 6], wy[r0 + 7]};
+                    pma = V2{wm[r0 + 4], wm[r0 + 5]}; pmb = V2{wm[r0 + 6], wm[r0 + 7]};
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 const V2 dxa = xa - ownx, dxb = xb - ownx;
                 const V2 dya = ya - owny, dyb = yb - owny;
