@@ -91,6 +91,46 @@ __global__ __launch_bounds__(256) void probe(unsigned long long* cyc, float* out
                 F = F + (da * m) * inv.x;
                 F = F + (db * m) * inv.y;
                 (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
+            } else if (MODE == 4 || MODE == 5) {
+                // The round-3 ring kernel's sequence: four walk positions per batch, EVERY instruction packed over two
+                // positions (component-major operands), two packed chains side by side, 64 scalar chain adds per 32
+                // positions; MODE 5 adds the v_min3 screen of the non-zero-radius case.  8.5 packed + 2 transcendental
+                // + 2 adds per pair.
+                if (u & 3) continue;
+                float2_ xa = {rec.x, rec.x + 0.5f}, xb = {recb.x, recb.x + 0.25f};
+                float2_ ya = {rec.y, rec.y + 0.5f}, yb = {recb.y, recb.y - 0.25f};
+                float2_ ma = {m, m + 1.0f}, mb = {m + 2.0f, m + 3.0f};
+                asm volatile("" : "+v"(xa), "+v"(xb), "+v"(ya), "+v"(yb), "+v"(ma), "+v"(mb));
+                const float2_ ownx = {pi.x, pi.x}, owny = {pi.y, pi.y};
+                const float2_ dxa = xa - ownx, dxb = xb - ownx, dya = ya - owny, dyb = yb - owny;
+                const float2_ sxa = dxa * dxa, sxb = dxb * dxb, sya = dya * dya, syb = dyb * dyb;
+                const float2_ d2a = sxa + sya, d2b = sxb + syb;
+                if (MODE == 5) {
+                    float closest = m;
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2a.x), "v"(d2a.y));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(closest) : "v"(closest), "v"(d2b.x), "v"(d2b.y));
+                    m = closest * 0.0f + m;
+                }
+                float2_ ya_, yb_;
+                ya_.x = __builtin_amdgcn_rsqf(d2a.x); ya_.y = __builtin_amdgcn_rsqf(d2a.y);
+                yb_.x = __builtin_amdgcn_rsqf(d2b.x); yb_.y = __builtin_amdgcn_rsqf(d2b.y);
+                const float2_ ga = d2a * ya_, gb = d2b * yb_, ha = ya_ * 0.5f, hb = yb_ * 0.5f;
+                const float2_ ea = __builtin_elementwise_fma(-ga, ga, d2a), eb = __builtin_elementwise_fma(-gb, gb, d2b);
+                const float2_ da = __builtin_elementwise_fma(ea, ha, ga), db = __builtin_elementwise_fma(eb, hb, gb);
+                const float2_ ca = (da * da) * da, cb = (db * db) * db;
+                float2_ ra, rb;
+                ra.x = __builtin_amdgcn_rcpf(ca.x); ra.y = __builtin_amdgcn_rcpf(ca.y);
+                rb.x = __builtin_amdgcn_rcpf(cb.x); rb.y = __builtin_amdgcn_rcpf(cb.y);
+                const float2_ one = {1.0f, 1.0f};
+                const float2_ fa = __builtin_elementwise_fma(-ca, ra, one), fb = __builtin_elementwise_fma(-cb, rb, one);
+                const float2_ inva = __builtin_elementwise_fma(fa, ra, ra), invb = __builtin_elementwise_fma(fb, rb, rb);
+                const float2_ txa = (dxa * ma) * inva, txb = (dxb * mb) * invb, tya = (dya * ma) * inva, tyb = (dyb * mb) * invb;
+                F.x = F.x + txa.x; asm("" : "+v"(F.x)); F.y = F.y + tya.x;
+                F.x = F.x + txa.y; asm("" : "+v"(F.x)); F.y = F.y + tya.y;
+                F.x = F.x + txb.x; asm("" : "+v"(F.x)); F.y = F.y + tyb.x;
+                F.x = F.x + txb.y; asm("" : "+v"(F.x)); F.y = F.y + tyb.y;
+                rec.x += 3e-3f; recb.x += 4e-3f;
+                (void)d; (void)sq; (void)tt; (void)d2; (void)y; (void)g; (void)h; (void)e; (void)dd; (void)c; (void)r;
             } else {           // same work with scalar (non-packed) ops only: 22 VALU
                 float dx, dy, a2, b2, mx, my, tx, ty;
                 asm volatile(
@@ -160,5 +200,7 @@ int main() {
     run<1>("scalar ops only", d_cyc, d_out);
     run<2>("chain packed across 2", d_cyc, d_out);
     run<3>("... and no v_rcp", d_cyc, d_out);
+    run<4>("r03 ring sequence", d_cyc, d_out);
+    run<5>("r03 ring seq + v_min3", d_cyc, d_out);
     return 0;
 }
