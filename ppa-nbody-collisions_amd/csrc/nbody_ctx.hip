@@ -740,6 +740,11 @@ int nbody_group_step(nbody_ctx** ctxs, int world, int nsteps) {
             return nbody_fail(NBODY_ERR_STATE, "nbody_group_step: context %d is not rank %d of %d (or not uploaded)", g, g, world);
         if (world > 1 && !(c->desc.flags & NBODY_FLAG_GROUP_EXCHANGE))
             return nbody_fail(NBODY_ERR_STATE, "nbody_group_step: context %d lacks NBODY_FLAG_GROUP_EXCHANGE", g);
+        // the ranks lay their slots out from the same history (refresh_bound): they must have been uploaded and stepped together
+        if (c->enq != ctxs[0]->enq || c->xchg_n != ctxs[0]->xchg_n)
+            return nbody_fail(NBODY_ERR_STATE, "nbody_group_step: context %d is at step %lld with bound %d, context 0 at step %lld "
+                                               "with bound %d (upload and step the group together)",
+                              g, (long long)c->enq, c->xchg_n, (long long)ctxs[0]->enq, ctxs[0]->xchg_n);
     }
     // direct xGMI copies between the ranks' devices (ignored where already enabled / same device)
     for (int g = 0; g < world; ++g)

@@ -773,6 +773,23 @@ def test_exchange_follows_the_live_count(nb):
     grp.close(); one.close()
 
 
+def test_group_ranks_must_share_their_history(nb):
+    """The ranks of a group lay their slots out from the same history of body counts: a rank that was uploaded again on its
+    own is refused (NBODY_ERR_STATE) instead of exchanging slots of another layout."""
+    cfg = nb.stock_config(particleCount=2048, fieldWidth=8000, fieldHeight=8000)
+    bodies = nb.init_bodies(cfg)
+    grp = nb.StepperGroup(2, cfg=cfg)
+    grp.upload(bodies)
+    grp.step(6)
+    grp.ranks[1].upload(bodies)
+    with pytest.raises(nb.NbodyError) as e:
+        grp.step(1)
+    assert e.value.status == -9 and "together" in str(e.value)
+    grp.upload(bodies)
+    grp.step(2)
+    grp.close()
+
+
 def test_group_context_alone_cannot_assemble_the_state(nb):
     """A rank of a group has its own velocities only: downloading it by itself returns the replica with zero velocities
     outside its range (documented), the group download returns the whole state."""
