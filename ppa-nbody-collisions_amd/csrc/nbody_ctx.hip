@@ -432,7 +432,7 @@ int launch_commit(nbody_ctx* c) {
     const int gx_all = (slot_bodies(c) + 255) / 256 > 0 ? (slot_bodies(c) + 255) / 256 : 1;
     hipLaunchKernelGGL((unpack_slots<T>), dim3(gx_all, c->desc.world), dim3(256), 0, c->stream,
                        (const unsigned char*)c->gather, slot_stride(c), slot_bodies(c), c->desc.world, c->desc.rank,
-                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta, c->tile_rmax, c->Jt);
+                       (Rec<T>*)c->J, (Vec2<T>*)c->Vown, c->meta, c->tile_rmax, c->Jt, c->counters);
     HIP_TRY(hipGetLastError());
     return NBODY_OK;
 }

@@ -73,7 +73,8 @@ struct Counters {
 // Send slot of one rank for the per-step exchange: header + compacted survivors of the own range.
 struct SlotHeader {
     int count;
-    int pad[7];
+    int layout;                  // bodies the slot is laid out for (records at +32, velocities behind `layout` records)
+    int pad[6];
 };
 static_assert(sizeof(SlotHeader) == 32, "slot header is 32 bytes so fp64 records stay 32-byte aligned");
 
@@ -1471,6 +1472,7 @@ __global__ __launch_bounds__(kCompactBlock) void compact_scatter(const Rec<T>* _
             int tot = s;
             for (int w = 0; w < kCompactBlock / kWave; ++w) tot += wsum[w];
             slot_hdr->count = tot;
+            slot_hdr->layout = (int)(reinterpret_cast<const Rec<T>*>(slot_vels) - slot_recs);
         }
     }
     __syncthreads();
@@ -1490,18 +1492,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void unpack_slots(const unsigned char* __restrict__ gather, size_t slot_bytes,
                                                     int cap_own, int world, int rank, Rec<T>* __restrict__ J,
                                                     Vec2<T>* __restrict__ Vown, Meta* __restrict__ meta,
-                                                    unsigned* __restrict__ tile_rmax, float* __restrict__ Jt) {
+                                                    unsigned* __restrict__ tile_rmax, float* __restrict__ Jt,
+                                                    Counters* __restrict__ ctr) {
     const int g = blockIdx.y;
     int off = 0, total = 0;
+    bool bad_header = false;
+    // A header that does not fit the layout this rank unpacks with - another rank laid its slot out differently, or the
+    // gather brought something else - must not become an index: counts are clamped to the layout and the step is
+    // reported as failed (Counters::errors, like the ring kernel's index checks).
+    auto count_of = [&](int h) -> int {
+        const SlotHeader* hd = reinterpret_cast<const SlotHeader*>(gather + (size_t)h * slot_bytes);
+        const int c = hd->count;
+        if (c < 0 || c > cap_own || hd->layout != cap_own) { bad_header = true; return c < 0 ? 0 : (c > cap_own ? cap_own : c); }
+        return c;
+    };
     for (int h = 0; h < world; ++h) {
-        const int c = reinterpret_cast<const SlotHeader*>(gather + (size_t)h * slot_bytes)->count;
+        const int c = count_of(h);
         if (h < g) off += c;
         total += c;
     }
+    if (bad_header && g == 0 && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&ctr->errors, kIndexError);
     int lo, cnt;
     nbody_own_range_of(total, rank, world, &lo, &cnt);       // csrc/nbody_partition.h
     const unsigned char* slot = gather + (size_t)g * slot_bytes;
-    const int c = reinterpret_cast<const SlotHeader*>(slot)->count;
+    const int c = count_of(g);
     const Rec<T>* recs = reinterpret_cast<const Rec<T>*>(slot + sizeof(SlotHeader));
     const Vec2<T>* vels = reinterpret_cast<const Vec2<T>*>(slot + sizeof(SlotHeader) + (size_t)cap_own * sizeof(Rec<T>));
     const int q = blockIdx.x * 256 + threadIdx.x;
