@@ -32,22 +32,28 @@ while time.time() - t0 < budget:
     world = int(rng.choice([1, 1, 2, 3, 5, 8]))
     steps = int(rng.integers(2, 12))              # beyond 4 steps the slot layout follows the count four steps back
     log = bool(rng.integers(0, 3) == 0)             # the event-logging builds of the kernels, events checked too
+    f64 = bool(rng.integers(0, 5) == 0)             # one case in five in fp64 (the one-lane production kernel / general kernel)
+    precision = nb.F64 if f64 else nb.F32
+    if f64:
+        variant = int(rng.choice([0, 0, 1]))
     cfg = nb.stock_config(particleCount=n, fieldWidth=field, fieldHeight=field, minRadius=min_r, maxRadius=max_r,
                           maxRandBodyMass=max_m)
-    bodies = nb.init_bodies(cfg)
+    bodies = nb.init_bodies(cfg, precision)
     bodies.Velocities[:] = rng.uniform(-50, 50, size=(n, 2)).astype(np.float32)
+    dt, gr = (float(DT), float(GROWTH)) if f64 else (DT, GROWTH)
+    u = np.uint64 if f64 else np.uint32
     if rng.integers(0, 3) == 0:                      # a few coincident bodies: collisions even at radius 0
         k = int(rng.integers(1, 6))
         src, dst = rng.integers(0, n, k), rng.integers(0, n, k)
         bodies.Positions[dst] = bodies.Positions[src]
-    grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant, record_events=log)
+    grp = nb.StepperGroup(world, cfg=cfg, semantics=sem, kernel_variant=variant, record_events=log, precision=precision)
     grp.upload(bodies)
     blk = bodies.contiguousData.copy()
     cur = n
     for s in range(steps):
         grp.step(1)
         n_before = cur
-        cur, ost, ab, de, _ = ol.port_step(blk, cur, DT, field, field, GROWTH, semantics=sem, want_events=log)
+        cur, ost, ab, de, _ = ol.port_step(blk, cur, dt, field, field, gr, semantics=sem, want_events=log)
         out = grp.download()
         ok_events = True
         if log:
@@ -61,10 +67,10 @@ while time.time() - t0 < budget:
                 got_del = sorted(set(int(e["i"]) for e in ev[ev["kind"] == 1]))
                 ok_events = got_abs == sorted((int(a), int(b)) for a, b in ab) and got_del == sorted(int(d) for d in de)
         if not (ok_events and out.numBodies == cur and
-                np.array_equal(out.block.view(np.uint32), blk[:6 * cur].view(np.uint32))):
+                np.array_equal(out.block.view(u), blk[:6 * cur].view(u))):
             fails += 1
-            print("FAIL case %d step %d: n=%d field=%d r=[%g,%g] m=%g sem=%d variant=%d world=%d log=%d events_ok=%d: got n=%d "
-                  "want %d" % (cases, s, n, field, min_r, max_r, max_m, sem, variant, world, log, ok_events, out.numBodies, cur),
+            print("FAIL case %d step %d: n=%d field=%d r=[%g,%g] m=%g sem=%d variant=%d world=%d log=%d f64=%d events_ok=%d: got n=%d "
+                  "want %d" % (cases, s, n, field, min_r, max_r, max_m, sem, variant, world, log, f64, ok_events, out.numBodies, cur),
                   flush=True)
             break
         if cur == 0:
